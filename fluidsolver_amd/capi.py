@@ -1,0 +1,263 @@
+"""ctypes binding of libfluidsolver_amd.so (the C ABI declared in include/fluidsolver_amd.h).
+
+There is no fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfluidsolver_amd.so")
+
+FSA_OK = 0
+PRECISION_F32, PRECISION_F64 = 0, 1
+BOUNDARY_VERBATIM, BOUNDARY_LEGACY_CLAMP = 0, 1
+TYPE_FLUID, TYPE_CLOTH, TYPE_BOUNDARY, TYPE_EMITTER, TYPE_RIGID = 0, 1, 2, 3, 4
+GRID_UNDEF = 99999999
+KERNEL_NAME_MAX = 32
+
+# every symbol include/fluidsolver_amd.h declares
+EXPORTS = (
+    "fsa_last_error", "fsa_version", "fsa_derive_params", "fsa_create", "fsa_destroy",
+    "fsa_copy_param_to_device", "fsa_set_stream", "fsa_synchronize", "fsa_upload", "fsa_num_particles",
+    "fsa_num_undef", "fsa_calc_hash", "fsa_sort_particle", "fsa_reorder_data_and_find_cell_start",
+    "fsa_sort_particles", "fsa_compute_pressure", "fsa_compute_force", "fsa_advect",
+    "fsa_rigid_particle_volume", "fsa_step", "fsa_readback_pos_color", "fsa_get_buffer", "fsa_set_buffer",
+    "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant",
+)
+
+
+class FsaError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """struct fsa_params"""
+    _fields_ = [
+        ("dx", C.c_double), ("gridxmin", C.c_double * 3), ("gridxmax", C.c_double * 3),
+        ("gridres", C.c_int * 3), ("gravity", C.c_double * 3), ("dt", C.c_double),
+        ("viscosity", C.c_double), ("spacing", C.c_double), ("smoothradius", C.c_double),
+        ("kspikydiff", C.c_double), ("kernel_cubic", C.c_double), ("kernel_cubic_gradient", C.c_double),
+        ("pressureK", C.c_double), ("boundary_visc", C.c_double), ("acceleration_limit", C.c_double),
+        ("boundary_mode", C.c_int), ("slab_z0", C.c_int), ("slab_nz", C.c_int),
+    ]
+
+    @property
+    def num_cells(self) -> int:
+        nz = self.slab_nz if self.slab_nz > 0 else self.gridres[2]
+        return self.gridres[0] * self.gridres[1] * nz
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * KERNEL_NAME_MAX), ("launches", C.c_int), ("total_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library once and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FsaError(f"{LIB_PATH} is missing: build it with `make -C fluidsolver_amd/csrc` "
+                       "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    H, P = C.c_void_p, C.POINTER(Params)
+    lib.fsa_last_error.restype = C.c_char_p
+    lib.fsa_last_error.argtypes = []
+    lib.fsa_version.restype = C.c_char_p
+    lib.fsa_version.argtypes = []
+    protos = {
+        "fsa_derive_params": [P, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "fsa_create": [P, C.c_int, C.c_int, C.c_int, C.POINTER(H)],
+        "fsa_destroy": [H],
+        "fsa_copy_param_to_device": [H, P],
+        "fsa_set_stream": [H, C.c_void_p],
+        "fsa_synchronize": [H],
+        "fsa_upload": [H, C.c_int] + [C.c_void_p] * 9,
+        "fsa_num_particles": [H, C.POINTER(C.c_int)],
+        "fsa_num_undef": [H, C.POINTER(C.c_int)],
+        "fsa_calc_hash": [H], "fsa_sort_particle": [H], "fsa_reorder_data_and_find_cell_start": [H],
+        "fsa_sort_particles": [H], "fsa_compute_pressure": [H], "fsa_compute_force": [H], "fsa_advect": [H],
+        "fsa_rigid_particle_volume": [H],
+        "fsa_step": [H, C.c_int],
+        "fsa_readback_pos_color": [H, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
+        "fsa_get_buffer": [H, C.c_char_p, C.c_void_p, C.c_size_t],
+        "fsa_set_buffer": [H, C.c_char_p, C.c_void_p, C.c_size_t],
+        "fsa_timing_enable": [H, C.c_int], "fsa_timing_reset": [H],
+        "fsa_timing_read": [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)],
+        "fsa_set_variant": [H, C.c_int],
+    }
+    for name, args in protos.items():
+        f = getattr(lib, name)
+        f.restype = C.c_int
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != FSA_OK:
+        raise FsaError(f"fluidsolver_amd error {rc}: {load().fsa_last_error().decode(errors='replace')}")
+
+
+def make_params(precision=PRECISION_F32, *, spacing, smoothratio, vmin, vmax, gravity=(0.0, -10.0, 0.0),
+                dt=0.0004, viscosity=0.05, pressureK=1119.0, boundary_visc=0.0, acceleration_limit=0.0,
+                boundary_mode=BOUNDARY_VERBATIM, slab_z0=0, slab_nz=0, **_ignored) -> Params:
+    """Parameter block as MultiphaseSPHSolver::ParseParam/LoadParam fill it."""
+    lib = load()
+    p = Params()
+    d3 = C.c_double * 3
+    check(lib.fsa_derive_params(C.byref(p), precision, spacing, smoothratio, d3(*vmin), d3(*vmax)))
+    p.gravity = d3(*gravity)
+    p.dt = dt
+    p.viscosity = viscosity
+    p.pressureK = pressureK
+    p.boundary_visc = boundary_visc
+    p.acceleration_limit = acceleration_limit
+    p.boundary_mode = boundary_mode
+    p.slab_z0 = slab_z0
+    p.slab_nz = slab_nz
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# name -> (kind, per-particle width); kind r = real, i = int, c = per-cell int
+BUFFERS = {
+    "pos": ("r", 3), "vel": ("r", 3), "force": ("r", 3), "v_star": ("r", 3), "normal": ("r", 3),
+    "color": ("r", 4), "mass": ("r", 1), "density": ("r", 1), "pressure": ("r", 1), "restDensity": ("r", 1),
+    "type": ("i", 1), "group": ("i", 1), "uniqueId": ("i", 1), "indexTable": ("i", 1),
+    "particleHash": ("i", 1), "particleIndex": ("i", 1),
+    "gridCellStart": ("c", 0), "gridCellEnd": ("c", 0), "cellStartDense": ("c", 1),
+}
+
+
+class Solver:
+    """Thin object wrapper over one fsa_solver handle."""
+
+    def __init__(self, params: Params, capacity: int, precision=PRECISION_F32, device: int = 0):
+        self.lib = load()
+        self.params = params
+        self.precision = precision
+        self.dtype = np.float32 if precision == PRECISION_F32 else np.float64
+        self.capacity = int(capacity)
+        self.num_cells = params.num_cells
+        self._h = C.c_void_p()
+        check(self.lib.fsa_create(C.byref(params), precision, self.capacity, device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.fsa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- data --------------------------------------------------------------------------
+    @property
+    def n(self) -> int:
+        n = C.c_int()
+        check(self.lib.fsa_num_particles(self._h, C.byref(n)))
+        return n.value
+
+    def upload(self, scene: dict) -> None:
+        dt = self.dtype
+        keep = []
+
+        def real(k, w, required=True):
+            if k not in scene or scene[k] is None:
+                if required:
+                    raise KeyError(k)
+                return None
+            a = np.ascontiguousarray(scene[k], dtype=dt)
+            keep.append(a)
+            return a
+
+        def integer(k, required=True):
+            if k not in scene or scene[k] is None:
+                if required:
+                    raise KeyError(k)
+                return None
+            a = np.ascontiguousarray(scene[k], dtype=np.int32)
+            keep.append(a)
+            return a
+
+        pos = real("pos", 3)
+        n = 0 if pos is None else pos.reshape(-1, 3).shape[0]
+        check(self.lib.fsa_upload(self._h, n, _ptr(pos), _ptr(real("vel", 3)), _ptr(real("color", 4, False)),
+                                  _ptr(real("normal", 3, False)), _ptr(integer("type")),
+                                  _ptr(integer("group", False)), _ptr(integer("uniqueId", False)),
+                                  _ptr(real("mass", 1)), _ptr(real("restDensity", 1))))
+
+    def get(self, name: str) -> np.ndarray:
+        kind, w = BUFFERS[name]
+        n = self.n
+        if kind == "r":
+            out = np.empty((n, w) if w > 1 else (n,), dtype=self.dtype)
+        elif kind == "i":
+            out = np.empty((n,), dtype=np.int32)
+        else:
+            out = np.empty((self.num_cells + w,), dtype=np.int32)
+        check(self.lib.fsa_get_buffer(self._h, name.encode(), _ptr(out), out.nbytes))
+        return out
+
+    def set(self, name: str, value) -> None:
+        kind, _ = BUFFERS[name]
+        a = np.ascontiguousarray(value, dtype=self.dtype if kind == "r" else np.int32)
+        check(self.lib.fsa_set_buffer(self._h, name.encode(), _ptr(a), a.nbytes))
+
+    def readback_pos_color(self):
+        n = self.n
+        pos = np.empty((n, 3), self.dtype)
+        col = np.empty((n, 4), self.dtype)
+        m = C.c_int()
+        check(self.lib.fsa_readback_pos_color(self._h, _ptr(pos), _ptr(col), C.byref(m)))
+        return pos, col
+
+    def num_undef(self) -> int:
+        n = C.c_int()
+        check(self.lib.fsa_num_undef(self._h, C.byref(n)))
+        return n.value
+
+    # -- the operator seam ------------------------------------------------------------
+    def copy_param_to_device(self, params: Params): check(self.lib.fsa_copy_param_to_device(self._h, C.byref(params))); self.params = params
+    def calc_hash(self): check(self.lib.fsa_calc_hash(self._h))
+    def sort_particle(self): check(self.lib.fsa_sort_particle(self._h))
+    def reorder(self): check(self.lib.fsa_reorder_data_and_find_cell_start(self._h))
+    def sort_particles(self): check(self.lib.fsa_sort_particles(self._h))
+    def compute_pressure(self): check(self.lib.fsa_compute_pressure(self._h))
+    def compute_force(self): check(self.lib.fsa_compute_force(self._h))
+    def advect(self): check(self.lib.fsa_advect(self._h))
+    def rigid_particle_volume(self): check(self.lib.fsa_rigid_particle_volume(self._h))
+    def step(self, nsteps: int = 1): check(self.lib.fsa_step(self._h, int(nsteps)))
+    def synchronize(self): check(self.lib.fsa_synchronize(self._h))
+    def set_stream(self, stream_ptr): check(self.lib.fsa_set_stream(self._h, C.c_void_p(stream_ptr)))
+    def set_variant(self, v: int): check(self.lib.fsa_set_variant(self._h, int(v)))
+
+    # -- measurement ------------------------------------------------------------------
+    def timing_enable(self, on=True): check(self.lib.fsa_timing_enable(self._h, 1 if on else 0))
+    def timing_reset(self): check(self.lib.fsa_timing_reset(self._h))
+
+    def timing_read(self) -> dict:
+        cap = 64
+        arr = (KernelTime * cap)()
+        cnt = C.c_int()
+        check(self.lib.fsa_timing_read(self._h, arr, cap, C.byref(cnt)))
+        return {arr[k].name.decode(): (arr[k].launches, arr[k].total_ms) for k in range(min(cnt.value, cap))}

@@ -1,0 +1,711 @@
+// C ABI of the particle-solver step (see include/fluidsolver_amd.h): handle management, upload /
+// read-back, call-order checks and the per-step orchestration.  No kernel lives in this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "fsa_solver.h"
+
+namespace fsa {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+static int kernel_id(Solver *s, const char *name) {
+    for (size_t k = 0; k < s->kernel_names.size(); k++)
+        if (s->kernel_names[k] == name) return (int)k;
+    s->kernel_names.push_back(name);
+    return (int)s->kernel_names.size() - 1;
+}
+
+static hipEvent_t take_event(Solver *s) {
+    if (!s->event_pool.empty()) {
+        hipEvent_t e = s->event_pool.back();
+        s->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ScopedTimer::ScopedTimer(Solver *solver, const char *name) : s(solver) {
+    if (!s->timing) return;
+    TimedLaunch t;
+    t.kernel_id = kernel_id(s, name);
+    t.start = take_event(s);
+    t.stop = take_event(s);
+    if (!t.start || !t.stop) return;
+    (void)hipEventRecord(t.start, s->stream);
+    stop = t.stop;
+    s->launches.push_back(t);
+}
+
+ScopedTimer::~ScopedTimer() {
+    if (stop) (void)hipEventRecord(stop, s->stream);
+}
+
+// ---- parameters --------------------------------------------------------------------------------
+template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T> &d) {
+    d.dx = (T)h.dx;
+    for (int a = 0; a < 3; a++) {
+        d.gmin[a] = (T)h.gridxmin[a];
+        d.gmax[a] = (T)h.gridxmax[a];
+        d.gres[a] = h.gridres[a];
+        d.gravity[a] = (T)h.gravity[a];
+    }
+    d.dt = (T)h.dt;
+    d.viscosity = (T)h.viscosity;
+    d.sr = (T)h.smoothradius;
+    d.kspikydiff = (T)h.kspikydiff;
+    d.kernel_cubic = (T)h.kernel_cubic;
+    d.pressureK = (T)h.pressureK;
+    d.boundary_visc = (T)h.boundary_visc;
+    d.accel_limit = (T)h.acceleration_limit;
+    d.boundary_mode = h.boundary_mode;
+    d.z0 = h.slab_nz > 0 ? h.slab_z0 : 0;
+    d.nz = h.slab_nz > 0 ? h.slab_nz : h.gridres[2];
+    d.num_cells = h.gridres[0] * h.gridres[1] * d.nz;
+}
+
+static int check_params(const fsa_params *p) {
+    if (!p) return fail(FSA_ERR_INVALID, "params is NULL");
+    for (int a = 0; a < 3; a++)
+        if (p->gridres[a] <= 0) return fail(FSA_ERR_INVALID, "gridres[%d] = %d must be positive", a, p->gridres[a]);
+    if (!(p->dx > 0)) return fail(FSA_ERR_INVALID, "dx must be positive");
+    if (!(p->smoothradius > 0)) return fail(FSA_ERR_INVALID, "smoothradius must be positive");
+    // the 27-cell walk covers the support only if a cell is at least one smoothing radius wide
+    if (p->dx < p->smoothradius) return fail(FSA_ERR_INVALID, "dx (%g) < smoothradius (%g)", p->dx, p->smoothradius);
+    if (p->slab_nz < 0 || p->slab_z0 < 0 || (p->slab_nz > 0 && p->slab_z0 + p->slab_nz > p->gridres[2]))
+        return fail(FSA_ERR_INVALID, "slab [%d, %d) outside the grid (%d layers)", p->slab_z0,
+                    p->slab_z0 + p->slab_nz, p->gridres[2]);
+    const int nz = p->slab_nz > 0 ? p->slab_nz : p->gridres[2];
+    const double cells = (double)p->gridres[0] * p->gridres[1] * nz;
+    if (cells >= (double)FSA_GRID_UNDEF)
+        return fail(FSA_ERR_INVALID, "%.0f cells: the cell id must stay below GRID_UNDEF (%u)", cells, FSA_GRID_UNDEF);
+    if (p->boundary_mode != FSA_BOUNDARY_VERBATIM && p->boundary_mode != FSA_BOUNDARY_LEGACY_CLAMP)
+        return fail(FSA_ERR_INVALID, "unknown boundary_mode %d", p->boundary_mode);
+    return FSA_OK;
+}
+
+static void free_all(Solver *s) {
+    Buffers &b = s->b;
+    void *ptrs[] = {b.posType[0], b.posType[1], b.velMass[0], b.velMass[1], b.restDensity[0], b.restDensity[1],
+                    b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.hash, b.slot,
+                    b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
+                    b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.indexTable};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &t : s->launches) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto e : s->event_pool) (void)hipEventDestroy(e);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+}
+
+template <typename P> static int dalloc(P *&ptr, size_t bytes, bool zero) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(FSA_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(p, 0, bytes);
+        if (e != hipSuccess) return fail(FSA_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    ptr = (P *)p;
+    return FSA_OK;
+}
+
+static int activate(Solver *s) {
+    FSA_HIP(hipSetDevice(s->device));
+    return FSA_OK;
+}
+
+// scratch device buffer for host<->device staging of one array
+struct Staging {
+    void *d = nullptr;
+    ~Staging() {
+        if (d) (void)hipFree(d);
+    }
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 256;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return fail(FSA_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return FSA_OK;
+    }
+};
+
+static void invalidate_order(Solver *s) {
+    s->hash_valid = s->perm_valid = s->sorted_valid = false;
+    s->index_table_valid = s->ref_cells_valid = false;
+}
+
+}  // namespace fsa
+
+using namespace fsa;
+
+#define NEED(s)                                                   \
+    do {                                                          \
+        if (!(s)) return fail(FSA_ERR_INVALID, "solver is NULL"); \
+        int _rc = activate(s);                                    \
+        if (_rc) return _rc;                                      \
+    } while (0)
+#define TRY(expr)          \
+    do {                   \
+        int _rc = (expr);  \
+        if (_rc) return _rc; \
+    } while (0)
+
+extern "C" {
+
+const char *fsa_last_error(void) { return g_err; }
+const char *fsa_version(void) { return "fluidsolver_amd 0.1 (gfx950)"; }
+
+int fsa_derive_params(fsa_params *p, int precision, double spacing, double smoothratio, const double vmin[3],
+                      const double vmax[3]) {
+    if (!p || !vmin || !vmax) return fail(FSA_ERR_INVALID, "NULL argument");
+    if (precision == FSA_PRECISION_F32) {
+        // MultiphaseSPHSolver.cpp:381,452-469 with `float` variables: pow(float, float) is the float
+        // overload, pow(float, int) promotes to double, the pi literals are double (3.141593f is not).
+        const float sp = (float)spacing;
+        const float sr = sp * (float)smoothratio;
+        p->spacing = sp;
+        p->smoothradius = sr;
+        p->dx = sr;
+        for (int a = 0; a < 3; a++) {
+            const float lo = (float)vmin[a], hi = (float)vmax[a];
+            p->gridxmin[a] = lo;
+            p->gridxmax[a] = hi;
+            p->gridres[a] = (int)roundf((hi - lo) / sr);
+        }
+        p->kspikydiff = (float)(-45.0f / (3.141592 * (double)powf(sr, 6.0f)));
+        p->kernel_cubic = (float)(1 / 3.141593 / pow((double)(sr / 2), 3.0));
+        p->kernel_cubic_gradient = (float)(1.5 / (double)3.141593f / pow((double)(sr / 2), 4.0));
+    } else if (precision == FSA_PRECISION_F64) {
+        const double sr = spacing * smoothratio;
+        p->spacing = spacing;
+        p->smoothradius = sr;
+        p->dx = sr;
+        for (int a = 0; a < 3; a++) {
+            p->gridxmin[a] = vmin[a];
+            p->gridxmax[a] = vmax[a];
+            p->gridres[a] = (int)round((vmax[a] - vmin[a]) / sr);
+        }
+        p->kspikydiff = -45.0f / (3.141592 * pow(sr, 6.0));
+        p->kernel_cubic = 1 / 3.141593 / pow(sr / 2, 3.0);
+        p->kernel_cubic_gradient = 1.5 / (double)3.141593f / pow(sr / 2, 4.0);
+    } else {
+        return fail(FSA_ERR_INVALID, "unknown precision %d", precision);
+    }
+    return FSA_OK;
+}
+
+int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa_solver **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    TRY(check_params(p));
+    if (precision != FSA_PRECISION_F32 && precision != FSA_PRECISION_F64)
+        return fail(FSA_ERR_INVALID, "unknown precision %d", precision);
+    if (capacity < 0) return fail(FSA_ERR_INVALID, "capacity %d < 0", capacity);
+    int ndev = 0;
+    FSA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(FSA_ERR_INVALID, "device %d of %d", device, ndev);
+
+    Solver *s = new (std::nothrow) Solver();
+    if (!s) return fail(FSA_ERR_NOMEM, "out of host memory");
+    s->precision = precision;
+    s->device = device;
+    s->capacity = capacity;
+    s->hp = *p;
+    to_dev_params(*p, s->pf);
+    to_dev_params(*p, s->pd);
+    s->num_cells = s->pf.num_cells;
+
+    int rc = activate(s);
+    if (rc == FSA_OK && hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(FSA_ERR_HIP, "hipStreamCreate failed");
+    s->stream = s->own_stream;
+
+    const size_t N = (size_t)capacity, R = s->real_size(), C = (size_t)s->num_cells;
+    const size_t nblocks = (N + kBlock - 1) / kBlock;
+    const size_t scan_tiles = (std::max(C, nblocks) + 1) / (kBlock * 8) + 4;
+    Buffers &b = s->b;
+#define ALLOC(field, bytes, zero) \
+    if (rc == FSA_OK) rc = dalloc(field, (bytes), (zero))
+    for (int k = 0; k < 2; k++) {
+        ALLOC(b.posType[k], N * 4 * R, true);
+        ALLOC(b.velMass[k], N * 4 * R, true);
+        ALLOC(b.restDensity[k], N * R, true);
+        ALLOC(b.uniqueId[k], N * sizeof(int), true);
+    }
+    // the reference leaves these uninitialised (cudaMalloc); zero is this implementation's choice
+    ALLOC(b.density, N * R, true);
+    ALLOC(b.pressure, N * R, true);  // MultiphaseSPHSolver.cpp:975 does clear this one
+    ALLOC(b.force, N * 3 * R, true);
+    ALLOC(b.v_star, N * 3 * R, true);
+    ALLOC(b.hash, N * sizeof(int), true);
+    ALLOC(b.slot, N * sizeof(int), true);
+    ALLOC(b.tmpIndex, N * sizeof(int), true);
+    ALLOC(b.tmpHash, N * sizeof(int), true);
+    ALLOC(b.sortedIndex, N * sizeof(int), true);
+    ALLOC(b.sortedHash, N * sizeof(int), true);
+    ALLOC(b.cellCount, (C + 8) * sizeof(int), true);
+    ALLOC(b.cellStart, (C + 8) * sizeof(int), true);
+    ALLOC(b.gridCellStart, C * sizeof(int), true);
+    ALLOC(b.gridCellEnd, C * sizeof(int), true);
+    ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
+    ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);
+    ALLOC(b.undefBlockStart, (nblocks + 8) * sizeof(int), true);
+    ALLOC(b.color, N * 4 * R, true);
+    ALLOC(b.normal, N * 3 * R, true);
+    ALLOC(b.group, N * sizeof(int), true);
+    ALLOC(b.indexTable, N * sizeof(int), true);
+#undef ALLOC
+    if (rc != FSA_OK) {
+        free_all(s);
+        delete s;
+        return rc;
+    }
+    *out = reinterpret_cast<fsa_solver *>(s);
+    return FSA_OK;
+}
+
+int fsa_destroy(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s) return FSA_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    free_all(s);
+    delete s;
+    return FSA_OK;
+}
+
+int fsa_copy_param_to_device(fsa_solver *hs, const fsa_params *p) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    TRY(check_params(p));
+    DevParams<float> nf;
+    to_dev_params(*p, nf);
+    if (nf.num_cells != s->num_cells || nf.gres[0] != s->pf.gres[0] || nf.gres[1] != s->pf.gres[1] ||
+        nf.gres[2] != s->pf.gres[2] || nf.z0 != s->pf.z0 || nf.nz != s->pf.nz)
+        return fail(FSA_ERR_INVALID, "grid resolution / slab differ from the ones the solver was created with");
+    s->hp = *p;
+    to_dev_params(*p, s->pf);
+    to_dev_params(*p, s->pd);
+    invalidate_order(s);
+    return FSA_OK;
+}
+
+int fsa_set_stream(fsa_solver *hs, void *hip_stream) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+    return FSA_OK;
+}
+
+int fsa_synchronize(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    return FSA_OK;
+}
+
+int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const void *color4, const void *normal3,
+               const int *type, const int *group, const int *uniqueId, const void *mass, const void *restDensity) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (n < 0 || n > s->capacity) return fail(FSA_ERR_CAPACITY, "n = %d exceeds capacity %d", n, s->capacity);
+    if (n > 0 && (!pos3 || !vel3 || !type || !mass || !restDensity))
+        return fail(FSA_ERR_INVALID, "pos, vel, type, mass and restDensity are required");
+    const size_t N = (size_t)n, R = s->real_size();
+    if (uniqueId) {
+        std::vector<unsigned char> seen(N, 0);
+        for (size_t i = 0; i < N; i++) {
+            const int u = uniqueId[i];
+            if (u < 0 || (size_t)u >= N || seen[u])
+                return fail(FSA_ERR_INVALID, "uniqueId must be a permutation of 0..n-1 (entry %zu = %d)", i, u);
+            seen[u] = 1;
+        }
+    }
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    s->n = n;
+    s->cur = 0;
+    invalidate_order(s);
+    if (n == 0) return FSA_OK;
+
+    Staging sp, sv, st, sm;
+    TRY(sp.alloc(N * 3 * R));
+    TRY(sv.alloc(N * 3 * R));
+    TRY(st.alloc(N * sizeof(int)));
+    TRY(sm.alloc(N * R));
+    FSA_HIP(hipMemcpy(sp.d, pos3, N * 3 * R, hipMemcpyHostToDevice));
+    FSA_HIP(hipMemcpy(sv.d, vel3, N * 3 * R, hipMemcpyHostToDevice));
+    FSA_HIP(hipMemcpy(st.d, type, N * sizeof(int), hipMemcpyHostToDevice));
+    FSA_HIP(hipMemcpy(sm.d, mass, N * R, hipMemcpyHostToDevice));
+    TRY(launch_pack(s, n, sp.d, sv.d, (const int *)st.d, sm.d));
+    FSA_HIP(hipMemcpy(s->b.restDensity[0], restDensity, N * R, hipMemcpyHostToDevice));
+
+    std::vector<int> uid(N);
+    for (size_t i = 0; i < N; i++) uid[i] = uniqueId ? uniqueId[i] : (int)i;
+    FSA_HIP(hipMemcpy(s->b.uniqueId[0], uid.data(), N * sizeof(int), hipMemcpyHostToDevice));
+
+    // colour, normal and group never change on this path: keep them in uniqueId order
+    auto store_static = [&](void *dst, const void *src, size_t elem_bytes) -> int {
+        if (!src) {
+            FSA_HIP(hipMemset(dst, 0, N * elem_bytes));
+            return FSA_OK;
+        }
+        std::vector<unsigned char> tmp(N * elem_bytes);
+        const unsigned char *in = (const unsigned char *)src;
+        for (size_t i = 0; i < N; i++) memcpy(&tmp[(size_t)uid[i] * elem_bytes], in + i * elem_bytes, elem_bytes);
+        FSA_HIP(hipMemcpy(dst, tmp.data(), N * elem_bytes, hipMemcpyHostToDevice));
+        return FSA_OK;
+    };
+    TRY(store_static(s->b.color, color4, 4 * R));
+    TRY(store_static(s->b.normal, normal3, 3 * R));
+    TRY(store_static(s->b.group, group, sizeof(int)));
+    // start from the zero state the constructor gives
+    FSA_HIP(hipMemset(s->b.force, 0, N * 3 * R));
+    FSA_HIP(hipMemset(s->b.v_star, 0, N * 3 * R));
+    FSA_HIP(hipMemset(s->b.density, 0, N * R));
+    FSA_HIP(hipMemset(s->b.pressure, 0, N * R));
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    return FSA_OK;
+}
+
+int fsa_num_particles(fsa_solver *hs, int *n) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s || !n) return fail(FSA_ERR_INVALID, "NULL argument");
+    *n = s->n;
+    return FSA_OK;
+}
+
+int fsa_num_undef(fsa_solver *hs, int *n) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!n) return fail(FSA_ERR_INVALID, "n is NULL");
+    if (!s->perm_valid && !s->sorted_valid) return fail(FSA_ERR_INVALID, "no sort has run on the current state");
+    int in_grid = 0;
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(hipMemcpy(&in_grid, s->b.cellStart + s->num_cells, sizeof(int), hipMemcpyDeviceToHost));
+    *n = s->n - in_grid;
+    return FSA_OK;
+}
+
+// ---- the operator seam -------------------------------------------------------------------------
+int fsa_calc_hash(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    TRY(launch_hash_count(s));
+    s->hash_valid = true;
+    s->perm_valid = false;
+    s->sorted_valid = false;
+    s->ref_cells_valid = false;
+    return FSA_OK;
+}
+
+int fsa_sort_particle(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->hash_valid) return fail(FSA_ERR_INVALID, "fsa_sort_particle needs fsa_calc_hash first");
+    TRY(launch_scan_cells(s));
+    TRY(launch_scatter(s));
+    TRY(launch_rank(s));
+    s->perm_valid = true;
+    return FSA_OK;
+}
+
+int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->perm_valid) return fail(FSA_ERR_INVALID, "reorder needs fsa_sort_particle first");
+    TRY(launch_reorder(s));
+    s->cur = 1 - s->cur;
+    s->sorted_valid = true;
+    s->hash_valid = false;  // hash[] described the previous order
+    s->perm_valid = false;
+    s->index_table_valid = false;
+    s->ref_cells_valid = false;
+    return FSA_OK;
+}
+
+int fsa_sort_particles(fsa_solver *hs) {
+    TRY(fsa_calc_hash(hs));
+    TRY(fsa_sort_particle(hs));
+    return fsa_reorder_data_and_find_cell_start(hs);
+}
+
+int fsa_compute_pressure(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "ComputePressure needs a sorted state");
+    return launch_density(s);
+}
+
+int fsa_compute_force(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "computeForce needs a sorted state");
+    return launch_force(s);
+}
+
+int fsa_advect(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    TRY(launch_advect(s));
+    // positions moved: the cell ranges no longer describe them
+    s->sorted_valid = false;
+    s->hash_valid = false;
+    s->perm_valid = false;
+    return FSA_OK;
+}
+
+int fsa_rigid_particle_volume(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "RigidParticleVolume needs a sorted state");
+    return launch_rigid_volume(s);
+}
+
+int fsa_step(fsa_solver *hs, int nsteps) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    for (int k = 0; k < nsteps; k++) {
+        TRY(fsa_sort_particles(hs));
+        TRY(launch_density(s));
+        TRY(launch_force(s));
+        TRY(fsa_advect(hs));
+    }
+    return FSA_OK;
+}
+
+// ---- read-back ---------------------------------------------------------------------------------
+int fsa_readback_pos_color(fsa_solver *hs, void *pos3, void *color4, int *n) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (n) *n = s->n;
+    const size_t N = (size_t)s->n, R = s->real_size();
+    if (N == 0) return FSA_OK;
+    if (pos3) {
+        Staging st;
+        TRY(st.alloc(N * 3 * R));
+        TRY(launch_unpack_vec3(s, s->b.posType[s->cur], st.d, s->n));
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(hipMemcpy(pos3, st.d, N * 3 * R, hipMemcpyDeviceToHost));
+    }
+    if (color4) {
+        Staging st;
+        TRY(st.alloc(N * 4 * R));
+        TRY(launch_gather_by_uid(s, s->b.color, st.d, s->n, (int)(4 * R / 4)));
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(hipMemcpy(color4, st.d, N * 4 * R, hipMemcpyDeviceToHost));
+    }
+    return FSA_OK;
+}
+
+static int copy_out(Solver *s, const void *dsrc, void *dst, size_t bytes) {
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    if (bytes) FSA_HIP(hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost));
+    return FSA_OK;
+}
+
+int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!name || (!dst && bytes)) return fail(FSA_ERR_INVALID, "NULL argument");
+    const size_t N = (size_t)s->n, R = s->real_size(), C = (size_t)s->num_cells;
+    const std::string k(name);
+    auto want = [&](size_t expect) -> int {
+        if (bytes != expect)
+            return fail(FSA_ERR_INVALID, "buffer '%s' is %zu bytes, caller passed %zu", name, expect, bytes);
+        return FSA_OK;
+    };
+    const int c = s->cur;
+    if (k == "pos" || k == "vel") {
+        TRY(want(N * 3 * R));
+        Staging st;
+        TRY(st.alloc(bytes));
+        TRY(launch_unpack_vec3(s, k == "pos" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n));
+        return copy_out(s, st.d, dst, bytes);
+    }
+    if (k == "type" || k == "mass") {
+        TRY(want(k == "type" ? N * sizeof(int) : N * R));
+        Staging st;
+        TRY(st.alloc(bytes));
+        TRY(launch_unpack_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
+        return copy_out(s, st.d, dst, bytes);
+    }
+    if (k == "color" || k == "normal" || k == "group") {
+        const size_t words = k == "color" ? 4 * R / 4 : k == "normal" ? 3 * R / 4 : 1;
+        TRY(want(N * words * 4));
+        Staging st;
+        TRY(st.alloc(bytes));
+        const void *table = k == "color" ? s->b.color : k == "normal" ? s->b.normal : (const void *)s->b.group;
+        TRY(launch_gather_by_uid(s, table, st.d, s->n, (int)words));
+        return copy_out(s, st.d, dst, bytes);
+    }
+    if (k == "force") { TRY(want(N * 3 * R)); return copy_out(s, s->b.force, dst, bytes); }
+    if (k == "v_star") { TRY(want(N * 3 * R)); return copy_out(s, s->b.v_star, dst, bytes); }
+    if (k == "density") { TRY(want(N * R)); return copy_out(s, s->b.density, dst, bytes); }
+    if (k == "pressure") { TRY(want(N * R)); return copy_out(s, s->b.pressure, dst, bytes); }
+    if (k == "restDensity") { TRY(want(N * R)); return copy_out(s, s->b.restDensity[c], dst, bytes); }
+    if (k == "uniqueId") { TRY(want(N * sizeof(int))); return copy_out(s, s->b.uniqueId[c], dst, bytes); }
+    if (k == "indexTable") {
+        TRY(want(N * sizeof(int)));
+        if (!s->index_table_valid) {
+            TRY(launch_index_table(s));
+            s->index_table_valid = true;
+        }
+        return copy_out(s, s->b.indexTable, dst, bytes);
+    }
+    if (k == "particleHash") {
+        TRY(want(N * sizeof(int)));
+        if (s->perm_valid) return copy_out(s, s->b.sortedHash, dst, bytes);
+        if (s->hash_valid) return copy_out(s, s->b.hash, dst, bytes);
+        if (s->sorted_valid) return copy_out(s, s->b.sortedHash, dst, bytes);
+        return fail(FSA_ERR_INVALID, "particleHash is not defined for the current state");
+    }
+    if (k == "particleIndex") {
+        TRY(want(N * sizeof(int)));
+        if (s->perm_valid || s->sorted_valid) return copy_out(s, s->b.sortedIndex, dst, bytes);
+        if (s->hash_valid) {  // calcHashD writes the identity, solver/sph_kernel_impl.cuh:110
+            int *o = (int *)dst;
+            for (size_t i = 0; i < N; i++) o[i] = (int)i;
+            return FSA_OK;
+        }
+        return fail(FSA_ERR_INVALID, "particleIndex is not defined for the current state");
+    }
+    if (k == "gridCellStart" || k == "gridCellEnd") {
+        TRY(want(C * sizeof(int)));
+        if (!s->sorted_valid && !s->perm_valid) return fail(FSA_ERR_INVALID, "no sort has run on the current state");
+        if (!s->ref_cells_valid) {
+            TRY(launch_ref_cells(s));
+            s->ref_cells_valid = true;
+        }
+        return copy_out(s, k == "gridCellStart" ? s->b.gridCellStart : s->b.gridCellEnd, dst, bytes);
+    }
+    if (k == "cellStartDense") {
+        TRY(want((C + 1) * sizeof(int)));
+        return copy_out(s, s->b.cellStart, dst, bytes);
+    }
+    return fail(FSA_ERR_UNKNOWN_NAME, "unknown buffer '%s'", name);
+}
+
+int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t bytes) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!name || (!src && bytes)) return fail(FSA_ERR_INVALID, "NULL argument");
+    const size_t N = (size_t)s->n, R = s->real_size();
+    const std::string k(name);
+    auto want = [&](size_t expect) -> int {
+        if (bytes != expect)
+            return fail(FSA_ERR_INVALID, "buffer '%s' is %zu bytes, caller passed %zu", name, expect, bytes);
+        return FSA_OK;
+    };
+    const int c = s->cur;
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    auto plain = [&](void *ddst, size_t expect) -> int {
+        TRY(want(expect));
+        if (bytes) FSA_HIP(hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice));
+        return FSA_OK;
+    };
+    if (k == "force") return plain(s->b.force, N * 3 * R);
+    if (k == "v_star") return plain(s->b.v_star, N * 3 * R);
+    if (k == "density") return plain(s->b.density, N * R);
+    if (k == "pressure") return plain(s->b.pressure, N * R);
+    if (k == "restDensity") return plain(s->b.restDensity[c], N * R);
+    if (k == "pos" || k == "vel") {
+        TRY(want(N * 3 * R));
+        Staging st;
+        TRY(st.alloc(bytes));
+        if (bytes) FSA_HIP(hipMemcpy(st.d, src, bytes, hipMemcpyHostToDevice));
+        TRY(launch_set_xyz(s, k == "pos" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n));
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        if (k == "pos") invalidate_order(s);
+        return FSA_OK;
+    }
+    if (k == "type" || k == "mass") {
+        TRY(want(k == "type" ? N * sizeof(int) : N * R));
+        Staging st;
+        TRY(st.alloc(bytes));
+        if (bytes) FSA_HIP(hipMemcpy(st.d, src, bytes, hipMemcpyHostToDevice));
+        TRY(launch_set_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        return FSA_OK;
+    }
+    return fail(FSA_ERR_UNKNOWN_NAME, "buffer '%s' cannot be set", name);
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+int fsa_timing_enable(fsa_solver *hs, int on) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    s->timing = on != 0;
+    return FSA_OK;
+}
+
+int fsa_timing_reset(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    for (auto &t : s->launches) {
+        s->event_pool.push_back(t.start);
+        s->event_pool.push_back(t.stop);
+    }
+    s->launches.clear();
+    return FSA_OK;
+}
+
+int fsa_timing_read(fsa_solver *hs, fsa_kernel_time *out, int cap, int *count) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!count || (cap > 0 && !out)) return fail(FSA_ERR_INVALID, "NULL argument");
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    const int K = (int)s->kernel_names.size();
+    std::vector<double> ms(K, 0.0);
+    std::vector<int> cnt(K, 0);
+    for (auto &t : s->launches) {
+        float e = 0.f;
+        FSA_HIP(hipEventElapsedTime(&e, t.start, t.stop));
+        ms[t.kernel_id] += e;
+        cnt[t.kernel_id]++;
+    }
+    int w = 0;
+    for (int k = 0; k < K; k++) {
+        if (cnt[k] == 0) continue;
+        if (w < cap) {
+            memset(&out[w], 0, sizeof(out[w]));
+            strncpy(out[w].name, s->kernel_names[k].c_str(), FSA_KERNEL_NAME_MAX - 1);
+            out[w].launches = cnt[k];
+            out[w].total_ms = ms[k];
+        }
+        w++;
+    }
+    *count = w;
+    return FSA_OK;
+}
+
+int fsa_set_variant(fsa_solver *hs, int variant) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
+    if (variant < 0 || variant > 1) return fail(FSA_ERR_INVALID, "unknown variant %d", variant);
+    s->variant = variant;
+    return FSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// Shared device-side definitions of the gfx950 particle-solver kernels.
+//
+// Arithmetic rule for every kernel in this directory: one IEEE rounding per
+// operation, in the operation order of the reference text (the translation
+// units are built with -ffp-contract=off, correctly rounded division and
+// sqrt).  Where the reference's unsuffixed literals promote a float
+// expression to double, the promotion is written out with explicit casts; for
+// T = double the casts are no-ops.  Citations are relative to
+// /root/reference/particle_solver.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/fluidsolver_amd.h"  // FSA_TYPE_*, FSA_GRID_UNDEF, FSA_BOUNDARY_*
+
+#define FSA_EPSILON 1e-10  // solver/cuda_common.cuh:10 (a double literal)
+
+namespace fsa {
+
+constexpr int kBlock = 256;  // 4 wavefronts of 64
+
+template <typename T> struct Vec4T;
+template <> struct Vec4T<float> { using type = float4; };
+template <> struct Vec4T<double> { using type = double4; };
+template <typename T> using Vec4 = typename Vec4T<T>::type;
+
+// tight 3-vector, the reference's cfloat3 layout (catpaw/geometry.h:58-60)
+template <typename T> struct Vec3 { T x, y, z; };
+
+// Particle type travels in the w lane of the position vector as raw bits.
+__device__ __forceinline__ float pack_int(int v, float) { return __int_as_float(v); }
+__device__ __forceinline__ double pack_int(int v, double) { return __longlong_as_double((long long)v); }
+__device__ __forceinline__ int unpack_int(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int unpack_int(double w) { return (int)__double_as_longlong(w); }
+
+// Hot-path fields of SimParam_SPH (solver/sph_solver.cuh:10-77) at the solver's precision.
+template <typename T> struct DevParams {
+    T dx;
+    T gmin[3];
+    T gmax[3];
+    int gres[3];   // global grid resolution
+    T gravity[3];
+    T dt;
+    T viscosity;
+    T sr;          // smoothradius
+    T kspikydiff;
+    T kernel_cubic;
+    T pressureK;
+    T boundary_visc;
+    T accel_limit;
+    int boundary_mode;
+    int z0;        // first global cell layer held by this solver
+    int nz;        // number of layers held (ghost layers included)
+    int num_cells; // gres[0] * gres[1] * nz
+};
+
+__device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float r_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double r_floor(double x) { return floor(x); }
+__device__ __forceinline__ float r_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double r_pow(double x, double y) { return pow(x, y); }
+
+// float -> int, saturating, NaN -> 0 (what cvt.rzi.s32.f32 gives the reference)
+template <typename T> __device__ __forceinline__ int to_int_sat(T v) {
+    if (v != v) return 0;
+    if (v >= (T)2147483647.0) return 2147483647;
+    if (v <= (T)-2147483648.0) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// calcGridPos, solver/sph_kernel_impl.cuh:74-80: global cell coordinates.
+template <typename T>
+__device__ __forceinline__ void calc_grid_pos(const DevParams<T> &P, T x, T y, T z, int &cx, int &cy, int &cz) {
+    cx = to_int_sat(r_floor((x - P.gmin[0]) / P.dx));
+    cy = to_int_sat(r_floor((y - P.gmin[1]) / P.dx));
+    cz = to_int_sat(r_floor((z - P.gmin[2]) / P.dx));
+}
+
+// calcGridHash, solver/sph_kernel_impl.cuh:58-72, on the layers this solver holds:
+// hash = y * gx * nz + (z - z0) * gx + x, GRID_UNDEF outside.
+template <typename T>
+__device__ __forceinline__ unsigned calc_grid_hash(const DevParams<T> &P, int cx, int cy, int cz) {
+    int lz = cz - P.z0;
+    if (cx < 0 || cx >= P.gres[0] || cy < 0 || cy >= P.gres[1] || cz < 0 || cz >= P.gres[2] || lz < 0 ||
+        lz >= P.nz)
+        return FSA_GRID_UNDEF;
+    return (unsigned)(cy * P.gres[0] * P.nz + lz * P.gres[0] + cx);
+}
+
+// Domain test of calcHashD, solver/sph_kernel_impl.cuh:95-100 (strict, compared in double).
+template <typename T> __device__ __forceinline__ bool in_domain(const DevParams<T> &P, T x, T y, T z) {
+    return (double)x < (double)P.gmax[0] - FSA_EPSILON && (double)x > (double)P.gmin[0] + FSA_EPSILON &&
+           (double)y < (double)P.gmax[1] - FSA_EPSILON && (double)y > (double)P.gmin[1] + FSA_EPSILON &&
+           (double)z < (double)P.gmax[2] - FSA_EPSILON && (double)z > (double)P.gmin[2] + FSA_EPSILON;
+}
+
+// Kernel_Cubic, solver/sph_kernel_impl.cuh:32-40.
+template <typename T> __device__ __forceinline__ T kernel_cubic(const DevParams<T> &P, T h, T x, T y, T z) {
+    T q = r_sqrt(x * x + y * y + z * z) / h;
+    T fq;
+    if (q >= 2) return 0;
+    if (q >= 1)
+        fq = (T)((double)((2 - q) * (2 - q) * (2 - q)) * 0.25);
+    else
+        fq = (T)((0.666667 - (double)(q * q) + 0.5 * (double)q * (double)q * (double)q) * 1.5);
+    return fq * P.kernel_cubic;
+}
+
+}  // namespace fsa

@@ -1,0 +1,345 @@
+// Uniform-grid neighbour search for gfx950: cell hash, per-cell counts, wavefront-scan
+// prefix sum, stable counting sort, SoA reorder.
+//
+// Replaces calcHashD / thrust::sort_by_key / reorderDataAndFindCellStartD
+// (solver/sph_kernel_impl.cuh:83-112, 116-200; solver/sph_solver.cu:30-77 under
+// /root/reference/particle_solver).  The reference sorts (hash, index) pairs with a stable radix
+// sort, so its order is: ascending cell, ties in previous array order, GRID_UNDEF last.  The key
+// range here is the cell count, so one counting sort does it:
+//   1. hash_count   : hash[i]; arrival slot inside the cell from an integer atomic (order inside a
+//                     cell is arbitrary at this point, the counts are exact); out-of-grid particles
+//                     get a stable rank inside their 256-particle block from wave ballots.
+//   2. scan         : exclusive prefix sum of the counts (and of the per-block out-of-grid counts).
+//   3. scatter      : tmpIndex[cellStart[h] + slot] = i.
+//   4. rank         : inside each cell, rank = number of entries with a smaller source index, which
+//                     turns the arbitrary arrival order into the stable one, deterministically.
+//   5. reorder      : gather the hot arrays through the permutation into the other buffer copy.
+#include "fsa_solver.h"
+
+namespace fsa {
+
+// ------------------------------------------------------------------------------------------------
+// 1. hash + count
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, const Vec4<T> *__restrict__ posType,
+                                                            int n, int *__restrict__ hash, int *__restrict__ slot,
+                                                            int *__restrict__ cellCount,
+                                                            int *__restrict__ undefBlockCount) {
+    __shared__ int waveCount[kBlock / 64];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    unsigned h = 0;
+    if (valid) {
+        Vec4<T> p = posType[i];
+        if (!in_domain(P, p.x, p.y, p.z)) {
+            h = FSA_GRID_UNDEF;
+        } else {
+            int cx, cy, cz;
+            calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
+            h = calc_grid_hash(P, cx, cy, cz);
+        }
+        hash[i] = (int)h;
+    }
+    const bool undef = valid && h == FSA_GRID_UNDEF;
+    int my = 0;
+    if (valid && !undef) my = atomicAdd(&cellCount[h], 1);
+
+    const unsigned long long m = __ballot(undef);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) waveCount[wave] = __popcll(m);
+    __syncthreads();
+    if (undef) {
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += waveCount[w];
+        my = base + __popcll(m & ((1ull << lane) - 1ull));
+    }
+    if (valid) slot[i] = my;
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kBlock / 64; w++) tot += waveCount[w];
+        undefBlockCount[blockIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. exclusive prefix sum of an int array (three launches: tile sums, scan of the sums, apply)
+// ------------------------------------------------------------------------------------------------
+constexpr int kScanPerThread = 8;
+constexpr int kScanTile = kBlock * kScanPerThread;
+
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over the block; returns the block total in `total`
+__device__ __forceinline__ int block_exclusive_scan(int v, int &total, int *smem /* >= blockDim/64 + 1 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = wave_inclusive_scan(v);
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) {
+        int c = smem[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_tile_sums_kernel(const int *__restrict__ in, int n,
+                                                                int *__restrict__ tileSums) {
+    __shared__ int smem[kBlock / 64 + 1];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanPerThread;
+    int sum = 0;
+    if (base + kScanPerThread <= n) {
+        const int4 a = *reinterpret_cast<const int4 *>(in + base);
+        const int4 b = *reinterpret_cast<const int4 *>(in + base + 4);
+        sum = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
+        for (int k = 0; k < kScanPerThread; k++)
+            if (base + k < n) sum += in[base + k];
+    }
+    int total;
+    block_exclusive_scan(sum, total, smem);
+    if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+
+// one block: in-place exclusive scan of tileSums[0..m), total to tileSums[m]
+__global__ __launch_bounds__(1024) void scan_sums_kernel(int *__restrict__ tileSums, int m) {
+    __shared__ int smem[1024 / 64 + 1];
+    int carry = 0;
+    for (int base = 0; base < m; base += 1024) {
+        const int idx = base + threadIdx.x;
+        const int v = idx < m ? tileSums[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, total, smem);
+        if (idx < m) tileSums[idx] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) tileSums[m] = carry;
+}
+
+// out[i] = sum of in[0..i); the thread that owns position n also writes out[n] = total
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int *__restrict__ in, int n,
+                                                            const int *__restrict__ tileSums,
+                                                            int *__restrict__ out) {
+    __shared__ int smem[kBlock / 64 + 1];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanPerThread;
+    int v[kScanPerThread];
+    const bool full = base + kScanPerThread <= n;
+    if (full) {
+        const int4 a = *reinterpret_cast<const int4 *>(in + base);
+        const int4 b = *reinterpret_cast<const int4 *>(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; k++) v[k] = (base + k < n) ? in[base + k] : 0;
+    }
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) sum += v[k];
+    int total;
+    int run = tileSums[blockIdx.x] + block_exclusive_scan(sum, total, smem);
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) {
+        // position n (one past the end) receives the grand total
+        if (base + k <= n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+static int exclusive_scan(Solver *s, const int *in, int n, int *out, int *tmp, const char *tag) {
+    const int tiles = (n + 1 + kScanTile - 1) / kScanTile;  // +1: out has n + 1 entries
+    ScopedTimer t(s, tag);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tiles), dim3(kBlock), 0, s->stream, in, n, tmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s->stream, tmp, tiles);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(kBlock), 0, s->stream, in, n, tmp, out);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. scatter source indices into their cells (arbitrary order inside a cell)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void scatter_kernel(int n, int num_cells, const int *__restrict__ hash,
+                                                         const int *__restrict__ slot,
+                                                         const int *__restrict__ cellStart,
+                                                         const int *__restrict__ undefBlockStart,
+                                                         int *__restrict__ tmpIndex, int *__restrict__ tmpHash) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned h = (unsigned)hash[i];
+    int p;
+    if (h != FSA_GRID_UNDEF)
+        p = cellStart[h] + slot[i];
+    else
+        p = cellStart[num_cells] + undefBlockStart[blockIdx.x] + slot[i];
+    tmpIndex[p] = i;
+    tmpHash[p] = (int)h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. stable rank inside each cell
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void rank_kernel(int n, const int *__restrict__ tmpIndex,
+                                                      const int *__restrict__ tmpHash,
+                                                      const int *__restrict__ cellStart,
+                                                      int *__restrict__ sortedIndex, int *__restrict__ sortedHash) {
+    const int sIdx = blockIdx.x * kBlock + threadIdx.x;
+    if (sIdx >= n) return;
+    const int i = tmpIndex[sIdx];
+    const unsigned h = (unsigned)tmpHash[sIdx];
+    int p = sIdx;  // out-of-grid particles are already in stable order
+    if (h != FSA_GRID_UNDEF) {
+        const int a = cellStart[h], b = cellStart[h + 1];
+        int r = 0;
+        for (int t = a; t < b; t++) r += (tmpIndex[t] < i) ? 1 : 0;
+        p = a + r;
+    }
+    sortedIndex[p] = i;
+    sortedHash[p] = (int)h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5. reorder: gather through the permutation
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void reorder_kernel(int n, const int *__restrict__ sortedIndex,
+                                                         const Vec4<T> *__restrict__ posTypeIn,
+                                                         const Vec4<T> *__restrict__ velMassIn,
+                                                         const T *__restrict__ restDensityIn,
+                                                         const int *__restrict__ uniqueIdIn,
+                                                         Vec4<T> *__restrict__ posTypeOut,
+                                                         Vec4<T> *__restrict__ velMassOut,
+                                                         T *__restrict__ restDensityOut,
+                                                         int *__restrict__ uniqueIdOut) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const int i = sortedIndex[p];
+    posTypeOut[p] = posTypeIn[i];
+    velMassOut[p] = velMassIn[i];
+    restDensityOut[p] = restDensityIn[i];
+    uniqueIdOut[p] = uniqueIdIn[i];
+}
+
+// gridCellStart / gridCellEnd in the reference's format (solver/sph_kernel_impl.cuh:151-163 after the
+// 0xff memset of solver/sph_solver.cu:65): start = 0xffffffff for an empty cell, end untouched there.
+__global__ __launch_bounds__(kBlock) void ref_cells_kernel(int num_cells, const int *__restrict__ cellStart,
+                                                           int *__restrict__ gridCellStart,
+                                                           int *__restrict__ gridCellEnd) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= num_cells) return;
+    const int a = cellStart[c], b = cellStart[c + 1];
+    if (b > a) {
+        gridCellStart[c] = a;
+        gridCellEnd[c] = b;
+    } else {
+        gridCellStart[c] = (int)0xffffffffu;
+    }
+}
+
+// indexTable[uniqueId[p]] = p, solver/sph_kernel_impl.cuh:179
+__global__ __launch_bounds__(kBlock) void index_table_kernel(int n, const int *__restrict__ uniqueId,
+                                                             int *__restrict__ indexTable) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    indexTable[uniqueId[p]] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+int launch_hash_count(Solver *s) {
+    const int n = s->n, nb = blocks_for(n);
+    {
+        ScopedTimer t(s, "clear_counts");
+        FSA_HIP(hipMemsetAsync(s->b.cellCount, 0, (size_t)s->num_cells * sizeof(int), s->stream));
+    }
+    if (n == 0) return FSA_OK;
+    ScopedTimer t(s, "hash_count");
+    if (s->precision == FSA_PRECISION_F32)
+        hipLaunchKernelGGL(hash_count_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, s->pf,
+                           (const float4 *)s->b.posType[s->cur], n, s->b.hash, s->b.slot, s->b.cellCount,
+                           s->b.undefBlockCount);
+    else
+        hipLaunchKernelGGL(hash_count_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, s->pd,
+                           (const double4 *)s->b.posType[s->cur], n, s->b.hash, s->b.slot, s->b.cellCount,
+                           s->b.undefBlockCount);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_scan_cells(Solver *s) {
+    int rc = exclusive_scan(s, s->b.cellCount, s->num_cells, s->b.cellStart, s->b.scanTmp, "scan_cells");
+    if (rc) return rc;
+    if (s->n == 0) return FSA_OK;
+    return exclusive_scan(s, s->b.undefBlockCount, blocks_for(s->n), s->b.undefBlockStart, s->b.scanTmp,
+                          "scan_undef");
+}
+
+int launch_scatter(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "scatter");
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n, s->num_cells,
+                       s->b.hash, s->b.slot, s->b.cellStart, s->b.undefBlockStart, s->b.tmpIndex, s->b.tmpHash);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_rank(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "rank");
+    hipLaunchKernelGGL(rank_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n, s->b.tmpIndex,
+                       s->b.tmpHash, s->b.cellStart, s->b.sortedIndex, s->b.sortedHash);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_reorder(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    const int in = s->cur, out = 1 - s->cur;
+    ScopedTimer t(s, "reorder");
+    if (s->precision == FSA_PRECISION_F32)
+        hipLaunchKernelGGL(reorder_kernel<float>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                           s->b.sortedIndex, (const float4 *)s->b.posType[in], (const float4 *)s->b.velMass[in],
+                           (const float *)s->b.restDensity[in], s->b.uniqueId[in], (float4 *)s->b.posType[out],
+                           (float4 *)s->b.velMass[out], (float *)s->b.restDensity[out], s->b.uniqueId[out]);
+    else
+        hipLaunchKernelGGL(reorder_kernel<double>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                           s->b.sortedIndex, (const double4 *)s->b.posType[in], (const double4 *)s->b.velMass[in],
+                           (const double *)s->b.restDensity[in], s->b.uniqueId[in], (double4 *)s->b.posType[out],
+                           (double4 *)s->b.velMass[out], (double *)s->b.restDensity[out], s->b.uniqueId[out]);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_ref_cells(Solver *s) {
+    ScopedTimer t(s, "ref_cells");
+    hipLaunchKernelGGL(ref_cells_kernel, dim3(blocks_for(s->num_cells)), dim3(kBlock), 0, s->stream, s->num_cells,
+                       s->b.cellStart, s->b.gridCellStart, s->b.gridCellEnd);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_index_table(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "index_table");
+    hipLaunchKernelGGL(index_table_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                       s->b.uniqueId[s->cur], s->b.indexTable);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+}  // namespace fsa

@@ -1,0 +1,123 @@
+// Host-side solver object behind the C ABI (include/fluidsolver_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fluidsolver_amd.h"
+#include "fsa_device.h"
+
+namespace fsa {
+
+// Device buffers of one solver.  Per-particle hot data is kept twice (index `cur` and `1 - cur`):
+// the counting-sort reorder gathers from one copy into the other and flips `cur`, which replaces the
+// reference's sorted->primary device copies (solver/sph_solver.cpp:58-84).
+struct Buffers {
+    // hot set, sorted order after a sort: {x, y, z, type bits}, {vx, vy, vz, mass}
+    void *posType[2] = {nullptr, nullptr};
+    void *velMass[2] = {nullptr, nullptr};
+    void *restDensity[2] = {nullptr, nullptr};
+    int *uniqueId[2] = {nullptr, nullptr};
+    // per-step results (index = current device order)
+    void *density = nullptr;
+    void *pressure = nullptr;
+    void *force = nullptr;   // tight 3-vectors
+    void *v_star = nullptr;  // tight 3-vectors
+    // neighbour search
+    int *hash = nullptr;         // cell of particle i (device order before the sort)
+    int *slot = nullptr;         // arrival slot inside its cell / rank among out-of-grid particles of its block
+    int *tmpIndex = nullptr;     // cell-grouped, unordered inside a cell
+    int *tmpHash = nullptr;
+    int *sortedIndex = nullptr;  // stable permutation ("particleIndex" after sortParticle)
+    int *sortedHash = nullptr;   // "particleHash" after sortParticle
+    int *cellCount = nullptr;    // num_cells
+    int *cellStart = nullptr;    // num_cells + 1, exclusive prefix of cellCount; [num_cells] = particles in grid
+    int *gridCellStart = nullptr;  // reference format (0xffffffff for an empty cell)
+    int *gridCellEnd = nullptr;
+    int *scanTmp = nullptr;
+    int *undefBlockCount = nullptr;
+    int *undefBlockStart = nullptr;
+    // attributes that never change on this path, stored once in uniqueId order
+    void *color = nullptr;   // 4 reals
+    void *normal = nullptr;  // 3 reals
+    int *group = nullptr;
+    int *indexTable = nullptr;
+};
+
+struct TimedLaunch {
+    int kernel_id;
+    hipEvent_t start, stop;
+};
+
+struct Solver {
+    int precision = FSA_PRECISION_F32;
+    int device = 0;
+    int capacity = 0;
+    int n = 0;
+    int num_cells = 0;
+    int cur = 0;
+    fsa_params hp{};  // as given by the caller
+    DevParams<float> pf{};
+    DevParams<double> pd{};
+    Buffers b;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // call-order state
+    bool hash_valid = false;    // hash/slot/cellCount describe the current arrays
+    bool perm_valid = false;    // sortedIndex/sortedHash/cellStart computed from hash
+    bool sorted_valid = false;  // current arrays are in sorted order and cellStart matches them
+    bool index_table_valid = false;
+    bool ref_cells_valid = false;
+    int variant = 1;
+    // timing
+    bool timing = false;
+    std::vector<std::string> kernel_names;
+    std::vector<TimedLaunch> launches;
+    std::vector<hipEvent_t> event_pool;
+
+    size_t real_size() const { return precision == FSA_PRECISION_F64 ? sizeof(double) : sizeof(float); }
+};
+
+// Sets the calling thread's error message and returns `code`.
+int fail(int code, const char *fmt, ...);
+
+#define FSA_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return ::fsa::fail(FSA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// Brackets one kernel launch with an event pair when timing is on.
+struct ScopedTimer {
+    Solver *s;
+    hipEvent_t stop = nullptr;
+    ScopedTimer(Solver *s, const char *name);
+    ~ScopedTimer();
+};
+
+// ---- launchers (fsa_grid.hip, fsa_sph.hip) ---------------------------------
+int launch_hash_count(Solver *s);
+int launch_scan_cells(Solver *s);
+int launch_scatter(Solver *s);
+int launch_rank(Solver *s);
+int launch_reorder(Solver *s);
+int launch_ref_cells(Solver *s);
+int launch_index_table(Solver *s);
+int launch_density(Solver *s);
+int launch_force(Solver *s);
+int launch_advect(Solver *s);
+int launch_rigid_volume(Solver *s);
+int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
+int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);
+int launch_unpack_w(Solver *s, const void *src4, void *dst, int n, bool as_int);
+int launch_gather_by_uid(Solver *s, const void *table, void *dst, int n, int words);
+int launch_set_xyz(Solver *s, void *dst4, const void *src3, int n);
+int launch_set_w(Solver *s, void *dst4, const void *src, int n, bool as_int);
+
+}  // namespace fsa

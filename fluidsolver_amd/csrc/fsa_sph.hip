@@ -1,0 +1,409 @@
+// WCSPH density / pressure, force and integration kernels for gfx950, plus the layout
+// conversion kernels used by upload / read-back.
+//
+// Generic (float and double) one-thread-per-particle kernels.  They restate
+// DensityCell/ComputePressureKernel, ForceCell/computeF, AdvectKernel and
+// RigidParticleVolumeKernel (solver/sph_kernel_impl.cuh:203-266, 269-373, 377-391, 2423-2473 under
+// /root/reference/particle_solver) on the sorted SoA layout.
+//
+// Cell walk.  The reference visits the 27 neighbour cells in the order z, y, x and each cell's
+// particles in ascending index.  The hash is x-fastest, so the three cells x-1, x, x+1 of one (y, z)
+// row are adjacent in the sorted arrays: the walk below visits 9 contiguous index ranges
+// [cellStart[row + xlo], cellStart[row + xhi + 1]) and thereby meets the neighbours in exactly the
+// reference's order (the per-particle sums are accumulated in that order).
+#include "fsa_solver.h"
+
+namespace fsa {
+
+template <typename T> struct RowWalk {
+    int cx, cy, cz, xlo, xhi;
+    bool any;
+    __device__ __forceinline__ RowWalk(const DevParams<T> &P, T x, T y, T z) {
+        calc_grid_pos(P, x, y, z, cx, cy, cz);
+        xlo = max(cx - 1, 0);
+        xhi = min(cx + 1, P.gres[0] - 1);
+        any = xlo <= xhi;
+    }
+    // index range of row (cy + dy, cz + dz); false when the row lies outside the held grid
+    __device__ __forceinline__ bool row(const DevParams<T> &P, const int *__restrict__ cellStart, int dy, int dz,
+                                        int &start, int &end) const {
+        const int y = cy + dy, z = cz + dz, lz = z - P.z0;
+        if (!any || y < 0 || y >= P.gres[1] || z < 0 || z >= P.gres[2] || lz < 0 || lz >= P.nz) return false;
+        const int base = (y * P.nz + lz) * P.gres[0];
+        start = cellStart[base + xlo];
+        end = cellStart[base + xhi + 1];
+        return true;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// density + Tait equation of state
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void density_kernel(DevParams<T> P, int n,
+                                                         const Vec4<T> *__restrict__ posType,
+                                                         const Vec4<T> *__restrict__ velMass,
+                                                         const T *__restrict__ restDensity,
+                                                         const int *__restrict__ cellStart,
+                                                         T *__restrict__ density, T *__restrict__ pressure) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    const Vec4<T> pi = posType[index];
+    const T mass_i = velMass[index].w;
+    const T rd_i = restDensity[index];
+    const T sr = P.sr, sr2 = sr * sr;
+    const T h = (T)((double)sr * 0.5);
+    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
+    T dens = 0;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const Vec4<T> pj = posType[j];
+                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const T d2 = xx * xx + xy * xy + xz * xz;
+                if (d2 >= sr2) continue;
+                const T wij = kernel_cubic(P, h, xx, xy, xz);
+                const int tj = unpack_int(pj.w);
+                if (tj == FSA_TYPE_FLUID) dens += mass_i * wij;
+                if (tj == FSA_TYPE_RIGID) dens += rd_i * restDensity[j] * wij;
+            }
+        }
+    density[index] = dens;
+    T pr = P.pressureK * (r_pow(dens / rd_i, (T)7) - 1);
+    if (pr < 0) pr = 0;
+    pressure[index] = pr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// force
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void force_kernel(DevParams<T> P, int n, const Vec4<T> *__restrict__ posType,
+                                                       const Vec4<T> *__restrict__ velMass,
+                                                       const T *__restrict__ density,
+                                                       const T *__restrict__ pressure,
+                                                       const int *__restrict__ cellStart,
+                                                       Vec3<T> *__restrict__ force) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    const Vec4<T> pi = posType[index];
+    if (unpack_int(pi.w) != FSA_TYPE_FLUID) return;  // force[index] keeps its old value
+    const Vec4<T> vi = velMass[index];
+    const T mass_i = vi.w;
+    const T dens_i = density[index], pres_i = pressure[index];
+    const T sr = P.sr, sr2 = sr * sr;
+    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
+    T fx = 0, fy = 0, fz = 0;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const Vec4<T> pj = posType[j];
+                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const T d2 = xx * xx + xy * xy + xz * xz;
+                const T d = r_sqrt(d2);
+                const int tj = unpack_int(pj.w);
+                if (j != index && tj == FSA_TYPE_FLUID) {
+                    if (d2 >= sr2) continue;
+                    const Vec4<T> vj = velMass[j];
+                    const T mass_j = vj.w, dens_j = density[j], pres_j = pressure[j];
+                    const T c = sr - d;
+                    const T nablaw = P.kspikydiff * c * c / d;
+                    const T pc = nablaw * mass_j * (pres_j / dens_j / dens_j + pres_i / dens_i / dens_i);
+                    fx += xx * pc * (T)(-1);
+                    fy += xy * pc * (T)(-1);
+                    fz += xz * pc * (T)(-1);
+                    const T vc = (T)((double)(nablaw * d2) / ((double)d2 + 0.01 * (double)sr2) * (double)mass_j /
+                                     (double)dens_j * 2 * (double)P.viscosity);
+                    fx += (vi.x - vj.x) * vc;
+                    fy += (vi.y - vj.y) * vc;
+                    fz += (vi.z - vj.z) * vc;
+                }
+                if (tj == FSA_TYPE_BOUNDARY) {
+                    const Vec4<T> vj = velMass[j];
+                    const T mass_j = vj.w;
+                    T B = 1;
+                    const T q = d / sr;
+                    if ((double)q < 0.66666)
+                        B = (T)((double)B * 0.66666);
+                    else if (q < 1)
+                        B = (T)((double)B * ((double)(2 * q) - 1.5 * (double)q * (double)q));
+                    else if (q < 2)
+                        B = (T)((double)B * (0.5 * (double)(2 - q) * (double)(2 - q)));
+                    else
+                        B = 0;
+                    B = (T)((double)B * (0.02 * 88.5 * 88.5 / (double)d));
+                    const T magnitude = mass_j / (mass_i + mass_j) * B;
+                    fx += xx * magnitude;
+                    fy += xy * magnitude;
+                    fz += xz * magnitude;
+                    const T vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
+                    const T xv = vx * xx + vy * xy + vz * xz;
+                    if (xv < 0) {
+                        const T c = sr - d;
+                        const T nablaw = P.kspikydiff * c * c / d;
+                        const T visc = (T)((double)(2 * P.boundary_visc * P.sr) * 88.5 / 2000);
+                        const T pi_ = (T)((double)(-visc * xv) / ((double)d2 + 0.01 * (double)sr2));
+                        fx += xx * pi_ * nablaw * mass_j * (T)(-1);
+                        fy += xy * pi_ * nablaw * mass_j * (T)(-1);
+                        fz += xz * pi_ * nablaw * mass_j * (T)(-1);
+                    }
+                }
+            }
+        }
+    Vec3<T> f;
+    f.x = fx + (T)0;
+    f.y = fy + (T)-9.8;  // the literal of solver/sph_kernel_impl.cuh:372, not the gravity parameter
+    f.z = fz + (T)0;
+    force[index] = f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// integration (+ legacy collision handling when boundary_mode == 1)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void advect_kernel(DevParams<T> P, int n, Vec4<T> *__restrict__ posType,
+                                                        Vec4<T> *__restrict__ velMass,
+                                                        const Vec3<T> *__restrict__ force,
+                                                        Vec3<T> *__restrict__ v_star) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    Vec4<T> p = posType[index];
+    const int type = unpack_int(p.w);
+    if (type == FSA_TYPE_RIGID) return;
+    if (P.boundary_mode == FSA_BOUNDARY_LEGACY_CLAMP && type == FSA_TYPE_BOUNDARY) return;
+    Vec4<T> v = velMass[index];
+    const Vec3<T> f = force[index];
+    v.x += f.x * P.dt;
+    v.y += f.y * P.dt;
+    v.z += f.z * P.dt;
+    p.x += v.x * P.dt;
+    p.y += v.y * P.dt;
+    p.z += v.z * P.dt;
+
+    T ax = P.gravity[0] - f.x, ay = P.gravity[1] - f.y, az = P.gravity[2] - f.z;
+    const T magnitude = r_sqrt(ax * ax + ay * ay + az * az);
+    if (magnitude > P.accel_limit) {
+        ax = ax / magnitude * P.accel_limit;
+        ay = ay / magnitude * P.accel_limit;
+        az = az / magnitude * P.accel_limit;
+    }
+    Vec3<T> vs;
+    vs.x = P.gravity[0] - ax;
+    vs.y = P.gravity[1] - ay;
+    vs.z = P.gravity[2] - az;
+    v_star[index] = vs;
+
+    if (P.boundary_mode == FSA_BOUNDARY_LEGACY_CLAMP) {
+        // clampBoundary, solver/新建文件夹/sph_kernel_impl.cuh:365-392: order y, x, z
+        if ((double)p.y < (double)P.gmin[1] + FSA_EPSILON) { p.y = (T)((double)P.gmin[1] + FSA_EPSILON); v.y = 0; }
+        if ((double)p.y > (double)P.gmax[1] - FSA_EPSILON) { p.y = (T)((double)P.gmax[1] - FSA_EPSILON); v.y = 0; }
+        if ((double)p.x < (double)P.gmin[0] + FSA_EPSILON) { p.x = (T)((double)P.gmin[0] + FSA_EPSILON); v.x = 0; }
+        if ((double)p.x > (double)P.gmax[0] - FSA_EPSILON) { p.x = (T)((double)P.gmax[0] - FSA_EPSILON); v.x = 0; }
+        if ((double)p.z < (double)P.gmin[2] + FSA_EPSILON) { p.z = (T)((double)P.gmin[2] + FSA_EPSILON); v.z = 0; }
+        if ((double)p.z > (double)P.gmax[2] - FSA_EPSILON) { p.z = (T)((double)P.gmax[2] - FSA_EPSILON); v.z = 0; }
+    }
+    posType[index] = p;
+    velMass[index] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rigid particle volume (set-up pass)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rigid_volume_kernel(DevParams<T> P, int n,
+                                                              const Vec4<T> *__restrict__ posType,
+                                                              const int *__restrict__ cellStart,
+                                                              T *__restrict__ restDensity) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    const Vec4<T> pi = posType[index];
+    if (unpack_int(pi.w) != FSA_TYPE_RIGID) return;
+    const T sr = P.sr, sr2 = sr * sr;
+    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
+    T sum = 0;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const Vec4<T> pj = posType[j];
+                if (unpack_int(pj.w) != FSA_TYPE_RIGID) continue;
+                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const T d2 = xx * xx + xy * xy + xz * xz;
+                if (d2 >= sr2) continue;
+                sum += kernel_cubic(P, sr / 2, xx, xy, xz);
+            }
+        }
+    restDensity[index] = 1 / sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion (upload / read-back / parity access)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(int n, const Vec3<T> *__restrict__ pos, const Vec3<T> *__restrict__ vel,
+                            const int *__restrict__ type, const T *__restrict__ mass, Vec4<T> *__restrict__ posType,
+                            Vec4<T> *__restrict__ velMass) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Vec3<T> p = pos[i], v = vel[i];
+    Vec4<T> a, b;
+    a.x = p.x; a.y = p.y; a.z = p.z; a.w = pack_int(type[i], (T)0);
+    b.x = v.x; b.y = v.y; b.z = v.z; b.w = mass[i];
+    posType[i] = a;
+    velMass[i] = b;
+}
+
+template <typename T>
+__global__ void unpack_vec3_kernel(int n, const Vec4<T> *__restrict__ src, Vec3<T> *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Vec4<T> a = src[i];
+    Vec3<T> o;
+    o.x = a.x; o.y = a.y; o.z = a.z;
+    dst[i] = o;
+}
+
+template <typename T>
+__global__ void unpack_w_kernel(int n, const Vec4<T> *__restrict__ src, void *__restrict__ dst, bool as_int) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T w = src[i].w;
+    if (as_int)
+        ((int *)dst)[i] = unpack_int(w);
+    else
+        ((T *)dst)[i] = w;
+}
+
+template <typename T>
+__global__ void set_xyz_kernel(int n, Vec4<T> *__restrict__ dst, const Vec3<T> *__restrict__ src) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Vec3<T> v = src[i];
+    Vec4<T> a = dst[i];
+    a.x = v.x; a.y = v.y; a.z = v.z;
+    dst[i] = a;
+}
+
+template <typename T>
+__global__ void set_w_kernel(int n, Vec4<T> *__restrict__ dst, const void *__restrict__ src, bool as_int) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Vec4<T> a = dst[i];
+    a.w = as_int ? pack_int(((const int *)src)[i], (T)0) : ((const T *)src)[i];
+    dst[i] = a;
+}
+
+// dst[p*words .. +words) = table[uniqueId[p]*words .. +words), 4-byte words
+__global__ void gather_by_uid_kernel(int n, int words, const int *__restrict__ uniqueId,
+                                     const int *__restrict__ table, int *__restrict__ dst) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * words) return;
+    const int p = (int)(t / words), w = (int)(t % words);
+    dst[t] = table[(long long)uniqueId[p] * words + w];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+#define FSA_DISPATCH(kernel, nthreads_total, ...)                                                         \
+    do {                                                                                                  \
+        if (s->precision == FSA_PRECISION_F32) {                                                          \
+            using T = float;                                                                              \
+            const DevParams<T> &P = s->pf;                                                                \
+            (void)P;                                                                                      \
+            hipLaunchKernelGGL(kernel<T>, dim3(blocks_for(nthreads_total)), dim3(kBlock), 0, s->stream,   \
+                               __VA_ARGS__);                                                              \
+        } else {                                                                                          \
+            using T = double;                                                                             \
+            const DevParams<T> &P = s->pd;                                                                \
+            (void)P;                                                                                      \
+            hipLaunchKernelGGL(kernel<T>, dim3(blocks_for(nthreads_total)), dim3(kBlock), 0, s->stream,   \
+                               __VA_ARGS__);                                                              \
+        }                                                                                                 \
+        FSA_HIP(hipGetLastError());                                                                       \
+    } while (0)
+
+int launch_density(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "density");
+    const int c = s->cur;
+    FSA_DISPATCH(density_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
+                 (const T *)s->b.restDensity[c], s->b.cellStart, (T *)s->b.density, (T *)s->b.pressure);
+    return FSA_OK;
+}
+
+int launch_force(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "force");
+    const int c = s->cur;
+    FSA_DISPATCH(force_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
+                 (const T *)s->b.density, (const T *)s->b.pressure, s->b.cellStart, (Vec3<T> *)s->b.force);
+    return FSA_OK;
+}
+
+int launch_advect(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "advect");
+    const int c = s->cur;
+    FSA_DISPATCH(advect_kernel, s->n, P, s->n, (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
+                 (const Vec3<T> *)s->b.force, (Vec3<T> *)s->b.v_star);
+    return FSA_OK;
+}
+
+int launch_rigid_volume(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "rigid_volume");
+    const int c = s->cur;
+    FSA_DISPATCH(rigid_volume_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], s->b.cellStart,
+                 (T *)s->b.restDensity[c]);
+    return FSA_OK;
+}
+
+int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass) {
+    if (n == 0) return FSA_OK;
+    const int c = s->cur;
+    FSA_DISPATCH(pack_kernel, n, n, (const Vec3<T> *)d_pos3, (const Vec3<T> *)d_vel3, d_type, (const T *)d_mass,
+                 (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c]);
+    return FSA_OK;
+}
+
+int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n) {
+    if (n == 0) return FSA_OK;
+    FSA_DISPATCH(unpack_vec3_kernel, n, n, (const Vec4<T> *)src4, (Vec3<T> *)dst3);
+    return FSA_OK;
+}
+
+int launch_unpack_w(Solver *s, const void *src4, void *dst, int n, bool as_int) {
+    if (n == 0) return FSA_OK;
+    FSA_DISPATCH(unpack_w_kernel, n, n, (const Vec4<T> *)src4, dst, as_int);
+    return FSA_OK;
+}
+
+int launch_set_xyz(Solver *s, void *dst4, const void *src3, int n) {
+    if (n == 0) return FSA_OK;
+    FSA_DISPATCH(set_xyz_kernel, n, n, (Vec4<T> *)dst4, (const Vec3<T> *)src3);
+    return FSA_OK;
+}
+
+int launch_set_w(Solver *s, void *dst4, const void *src, int n, bool as_int) {
+    if (n == 0) return FSA_OK;
+    FSA_DISPATCH(set_w_kernel, n, n, (Vec4<T> *)dst4, src, as_int);
+    return FSA_OK;
+}
+
+int launch_gather_by_uid(Solver *s, const void *table, void *dst, int n, int words) {
+    if (n == 0) return FSA_OK;
+    hipLaunchKernelGGL(gather_by_uid_kernel, dim3(blocks_for((long long)n * words)), dim3(kBlock), 0, s->stream, n,
+                       words, s->b.uniqueId[s->cur], (const int *)table, (int *)dst);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+}  // namespace fsa

@@ -1,0 +1,199 @@
+/*
+ * fluidsolver_amd.h -- C ABI of the MI355X (gfx950) particle-solver step.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, int status codes, an
+ * opaque solver handle.  It replaces the operator seam of the reference,
+ * particle_solver/solver/sph_solver.cuh:197-220 (CopyParam2Device, calcHash,
+ * sortParticle, reorderDataAndFindCellStart, ComputePressure, computeForce,
+ * Advect -- free functions taking the SimData_SPH struct of device pointers by
+ * value), plus the cudaMalloc / cudaMemcpy calls the reference's solver
+ * classes make inline (MultiphaseSPHSolver.cpp:10-27, 871-977;
+ * sph_solver.cpp:35-38).  All citations are relative to
+ * /root/reference/particle_solver.
+ *
+ * Host array layouts are the reference's: cfloat3 = 3 tightly packed reals,
+ * cfloat4 = 4 (catpaw/geometry.h:58-60, 519-520).  With precision
+ * FSA_PRECISION_F32 a "real" is a float; with FSA_PRECISION_F64 it is a double
+ * (the reference has no fp64 path; that mode exists for validation).
+ *
+ * Every function returns FSA_OK (0) or a negative FSA_ERR_* code;
+ * fsa_last_error() gives the message of the calling thread's last failure.
+ * Nothing here synchronises the device unless its comment says so.  A solver
+ * must be used from one host thread at a time.
+ */
+#ifndef FLUIDSOLVER_AMD_H
+#define FLUIDSOLVER_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSA_OK 0
+#define FSA_ERR_INVALID (-1)      /* bad argument / call order */
+#define FSA_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define FSA_ERR_NOMEM (-3)
+#define FSA_ERR_UNKNOWN_NAME (-4) /* buffer name not known */
+#define FSA_ERR_CAPACITY (-5)
+
+/* particle types, solver/particle_common.h:6-16 */
+#define FSA_TYPE_FLUID 0
+#define FSA_TYPE_CLOTH 1
+#define FSA_TYPE_BOUNDARY 2
+#define FSA_TYPE_EMITTER 3
+#define FSA_TYPE_RIGID 4
+#define FSA_TYPE_DEFORMABLE 5
+#define FSA_TYPE_GRANULAR 6
+
+/* solver/cuda_common.cuh:10-11 */
+#define FSA_GRID_UNDEF 99999999
+
+#define FSA_PRECISION_F32 0
+#define FSA_PRECISION_F64 1
+
+/* integration variants */
+#define FSA_BOUNDARY_VERBATIM 0     /* AdvectKernel, solver/sph_kernel_impl.cuh:377-391 */
+#define FSA_BOUNDARY_LEGACY_CLAMP 1 /* + skip TYPE_BOUNDARY and clamp to the grid box:
+                                       advectAndCollision / clampBoundary of the older snapshot,
+                                       solver/新建文件夹/sph_kernel_impl.cuh:365-403 */
+
+/*
+ * Hot-path fields of SimParam_SPH (solver/sph_solver.cuh:10-77), always in
+ * double here; the solver rounds them to its precision.  Replaces hParam /
+ * dParam (solver/sph_kernel_impl.cuh:13-14).
+ */
+typedef struct fsa_params {
+    double dx;
+    double gridxmin[3];
+    double gridxmax[3];
+    int gridres[3];
+    double gravity[3];
+    double dt;
+    double viscosity;
+    double spacing;
+    double smoothradius;
+    double kspikydiff;
+    double kernel_cubic;
+    double kernel_cubic_gradient;
+    double pressureK;
+    double boundary_visc;
+    double acceleration_limit;
+    int boundary_mode; /* FSA_BOUNDARY_* */
+    /* z-slab owned by this solver, in global cell layers [slab_z0, slab_z0 + slab_nz),
+     * ghost layers included; slab_nz = 0 means the whole grid. */
+    int slab_z0;
+    int slab_nz;
+} fsa_params;
+
+typedef struct fsa_solver fsa_solver;
+
+const char *fsa_last_error(void);
+const char *fsa_version(void);
+
+/*
+ * Derived constants of MultiphaseSPHSolver::LoadParam
+ * (solver/MultiphaseSPHSolver.cpp:381, 452-469): smoothradius, dx, gridres and
+ * the kernel normalisations, evaluated as a C++ compiler evaluates the
+ * reference's expressions for `float` (precision F32) or all in double (F64).
+ * Other fields of *p are left untouched.
+ */
+int fsa_derive_params(fsa_params *p, int precision, double spacing, double smoothratio,
+                      const double vmin[3], const double vmax[3]);
+
+/*
+ * Replaces SetupDeviceBuffer (MultiphaseSPHSolver.cpp:871-977) +
+ * CopyParam2Device (solver/sph_solver.cu:18-20).  `capacity` = maximum number
+ * of particles; `device` = HIP device ordinal.  Allocates every device buffer
+ * once; no later call allocates device memory.
+ */
+int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa_solver **out);
+int fsa_destroy(fsa_solver *s);
+
+/* CopyParam2Device, solver/sph_solver.cu:18-20.  The grid resolution and slab may not change. */
+int fsa_copy_param_to_device(fsa_solver *s, const fsa_params *p);
+
+/* Use the caller's hipStream_t for all work of this solver (NULL = the solver's own stream). */
+int fsa_set_stream(fsa_solver *s, void *hip_stream);
+int fsa_synchronize(fsa_solver *s);
+
+/*
+ * Replaces CopyParticleDataToDevice (solver/sph_solver.cpp:10-19,
+ * MultiphaseSPHSolver.cpp:10-27): host arrays in the reference layouts.
+ * color, normal, group may be NULL (zeros).  uniqueId may be NULL (0..n-1);
+ * otherwise it must be a permutation of 0..n-1 (the reference indexes
+ * indexTable with it).  Synchronises.
+ */
+int fsa_upload(fsa_solver *s, int n, const void *pos3, const void *vel3, const void *color4,
+               const void *normal3, const int *type, const int *group, const int *uniqueId,
+               const void *mass, const void *restDensity);
+
+int fsa_num_particles(fsa_solver *s, int *n);
+/* number of particles whose hash was GRID_UNDEF at the last sort (synchronises) */
+int fsa_num_undef(fsa_solver *s, int *n);
+
+/* ---- the operator seam, one entry per reference launcher ---------------- */
+/* calcHash, solver/sph_solver.cu:30-42 */
+int fsa_calc_hash(fsa_solver *s);
+/* sortParticle, solver/sph_solver.cu:46-53: afterwards "particleHash" is sorted ascending and
+ * "particleIndex" is the stable permutation. */
+int fsa_sort_particle(fsa_solver *s);
+/* reorderDataAndFindCellStart, solver/sph_solver.cu:57-77, together with the sorted->primary
+ * device copies of SPHSolver::SortParticles (solver/sph_solver.cpp:58-84), which become a
+ * buffer swap: afterwards "pos", "vel", ... are in sorted order. */
+int fsa_reorder_data_and_find_cell_start(fsa_solver *s);
+/* SPHSolver::SortParticles (solver/sph_solver.cpp:50-85) in one call */
+int fsa_sort_particles(fsa_solver *s);
+/* ComputePressure / computeForce / Advect, solver/sph_solver.cu:80-108 */
+int fsa_compute_pressure(fsa_solver *s);
+int fsa_compute_force(fsa_solver *s);
+int fsa_advect(fsa_solver *s);
+/* RigidParticleVolume (solver/sph_kernel_impl.cuh:2423-2473): restDensity of TYPE_RIGID particles
+ * = 1 / sum of W over rigid neighbours.  Needs a sorted state. */
+int fsa_rigid_particle_volume(fsa_solver *s);
+
+/* nsteps x SPHSolver::SolveSPH (solver/sph_solver.cpp:87-98) without the host read-back;
+ * fully asynchronous on the solver's stream. */
+int fsa_step(fsa_solver *s, int nsteps);
+
+/*
+ * CopyPosColorFromDevice (solver/sph_solver.cpp:35-38): positions and colours
+ * in the current device order (the order of the last sort).  Either pointer
+ * may be NULL.  Synchronises.
+ */
+int fsa_readback_pos_color(fsa_solver *s, void *pos3, void *color4, int *n);
+
+/*
+ * Debug / parity access to one named array in the reference's layout, current
+ * device order.  Names: pos vel force v_star normal (n x 3 reals); color
+ * (n x 4 reals); mass density pressure restDensity (n reals); type group
+ * uniqueId indexTable particleHash particleIndex (n ints); gridCellStart
+ * gridCellEnd (num_cells ints; gridCellEnd is only meaningful where
+ * gridCellStart != 0xffffffff, as in the reference); cellStartDense
+ * (num_cells + 1 ints, exclusive prefix of the per-cell counts).
+ * `bytes` must be the exact size.  Both synchronise.
+ */
+int fsa_get_buffer(fsa_solver *s, const char *name, void *dst, size_t bytes);
+/* settable: pos vel force v_star mass density pressure restDensity type */
+int fsa_set_buffer(fsa_solver *s, const char *name, const void *src, size_t bytes);
+
+/* ---- measurement ------------------------------------------------------ */
+#define FSA_KERNEL_NAME_MAX 32
+typedef struct fsa_kernel_time {
+    char name[FSA_KERNEL_NAME_MAX];
+    int launches;
+    double total_ms;
+} fsa_kernel_time;
+/* Record a HIP event pair around every kernel launched on the solver's stream. */
+int fsa_timing_enable(fsa_solver *s, int on);
+int fsa_timing_reset(fsa_solver *s);
+/* Synchronises; fills up to `cap` entries, *count = number of distinct kernels seen. */
+int fsa_timing_read(fsa_solver *s, fsa_kernel_time *out, int cap, int *count);
+
+/* variant switches for A/B measurement: 0 = generic kernels, 1 = tuned fp32 kernels (default) */
+int fsa_set_variant(fsa_solver *s, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

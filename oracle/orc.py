@@ -1,0 +1,186 @@
+"""ctypes front end of the CPU oracle (oracle/sph_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg as the checker / timed baseline.  The product
+package never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+TYPE_FLUID, TYPE_CLOTH, TYPE_BOUNDARY, TYPE_EMITTER, TYPE_RIGID = 0, 1, 2, 3, 4
+GRID_UNDEF = 99999999
+
+_VEC3 = ("pos", "vel", "normal", "force", "v_star",
+         "sortedPos", "sortedVel", "sortedNormal", "sortedV_star")
+_VEC4 = ("color", "sortedColor")
+_REAL1 = ("mass", "density", "pressure", "restDensity",
+          "sortedMass", "sortedRestDensity", "sorted_pressure")
+_INT1 = ("type", "group", "uniqueId", "indexTable", "sortedType", "sortedGroup",
+         "sortedUniqueId", "particleHash", "particleIndex")
+_CELL = ("gridCellStart", "gridCellEnd")
+
+# field order of struct orc_state in sph_oracle.h
+_STATE_FIELDS = (
+    "pos", "vel", "normal", "force", "v_star", "color",
+    "mass", "density", "pressure", "restDensity",
+    "type", "group", "uniqueId", "indexTable",
+    "sortedPos", "sortedVel", "sortedNormal", "sortedV_star", "sortedColor",
+    "sortedMass", "sortedRestDensity", "sorted_pressure",
+    "sortedType", "sortedGroup", "sortedUniqueId",
+    "particleHash", "particleIndex", "gridCellStart", "gridCellEnd",
+)
+
+
+def build(force: bool = False) -> None:
+    """Compile liborc32.so / liborc64.so with the committed Makefile."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def _make_types(real):
+    class Params(C.Structure):
+        _fields_ = [
+            ("dx", real), ("gridxmin", real * 3), ("gridxmax", real * 3), ("gridres", C.c_int * 3),
+            ("gravity", real * 3), ("dt", real), ("viscosity", real), ("spacing", real),
+            ("smoothradius", real), ("kspikydiff", real), ("kernel_cubic", real),
+            ("kernel_cubic_gradient", real), ("pressureK", real), ("boundary_visc", real),
+            ("acceleration_limit", real), ("boundary_mode", C.c_int),
+        ]
+
+    class State(C.Structure):
+        _fields_ = [("n", C.c_int), ("num_cells", C.c_int)] + [(f, C.c_void_p) for f in _STATE_FIELDS]
+
+    return Params, State
+
+
+class Oracle:
+    """One precision of the oracle: Oracle('f32') or Oracle('f64')."""
+
+    def __init__(self, precision: str = "f32"):
+        assert precision in ("f32", "f64")
+        self.precision = precision
+        self.real = C.c_float if precision == "f32" else C.c_double
+        self.dtype = np.float32 if precision == "f32" else np.float64
+        self.prefix = "orc_" if precision == "f32" else "orc64_"
+        path = os.path.join(_HERE, "liborc32.so" if precision == "f32" else "liborc64.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = C.CDLL(path)
+        self.Params, self.State = _make_types(self.real)
+        L, P, S = self.lib, C.POINTER(self.Params), C.POINTER(self.State)
+        self._fn("create", S, [C.c_int, C.c_int])
+        self._fn("destroy", None, [S])
+        self._fn("derive_params", None, [P, self.real, self.real, C.POINTER(self.real), C.POINTER(self.real)])
+        self._fn("set_threads", None, [C.c_int])
+        self._fn("get_threads", C.c_int, [])
+        for name in ("calc_hash", "reorder_data_and_find_cell_start", "sort_particles", "compute_pressure",
+                     "compute_force", "advect", "rigid_particle_volume"):
+            self._fn(name, None, [P, S])
+        self._fn("sort_particle", None, [S])
+        self._fn("copy_sorted_to_primary", None, [S])
+        self._fn("solve_sph", None, [P, S, C.c_int])
+
+    def _fn(self, name, restype, argtypes):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        f.argtypes = argtypes
+        setattr(self, "_" + name, f)
+
+    # -- parameters -------------------------------------------------
+    def make_params(self, spacing, smoothratio, vmin, vmax, *, gravity=(0.0, -10.0, 0.0), dt=0.0004,
+                    viscosity=0.05, pressureK=1119.0, boundary_visc=0.0, acceleration_limit=0.0,
+                    boundary_mode=0):
+        p = self.Params()
+        r3 = self.real * 3
+        self._derive_params(C.byref(p), spacing, smoothratio, r3(*vmin), r3(*vmax))
+        p.gravity = r3(*gravity)
+        p.dt = dt
+        p.viscosity = viscosity
+        p.pressureK = pressureK
+        p.boundary_visc = boundary_visc
+        p.acceleration_limit = acceleration_limit
+        p.boundary_mode = boundary_mode
+        return p
+
+    def set_threads(self, n: int) -> None:
+        self._set_threads(int(n))
+
+    def new_state(self, n: int, num_cells: int) -> "OracleState":
+        return OracleState(self, n, num_cells)
+
+
+class OracleState:
+    """Owns one orc_state; every array is exposed as a numpy view (no copy)."""
+
+    def __init__(self, orc: Oracle, n: int, num_cells: int):
+        self.orc = orc
+        self.n = n
+        self.num_cells = num_cells
+        self._s = orc._create(n, num_cells)
+        if not self._s:
+            raise MemoryError("orc_create failed")
+        st = self._s.contents
+        self.a = {}
+        for f in _STATE_FIELDS:
+            ptr = getattr(st, f)
+            if f in _VEC3:
+                shape, ct = (n, 3), orc.real
+            elif f in _VEC4:
+                shape, ct = (n, 4), orc.real
+            elif f in _REAL1:
+                shape, ct = (n,), orc.real
+            elif f in _INT1:
+                shape, ct = (n,), C.c_int
+            else:
+                shape, ct = (num_cells,), C.c_int
+            count = int(np.prod(shape))
+            if count == 0:
+                self.a[f] = np.zeros(shape, dtype=np.dtype(ct))
+            else:
+                buf = (ct * count).from_address(ptr)
+                self.a[f] = np.frombuffer(buf, dtype=np.dtype(ct)).reshape(shape)
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+    def load(self, scene: dict) -> None:
+        """Copy a scene dict (pos, vel, color, type, group, uniqueId, mass, restDensity, normal) in."""
+        n = self.n
+        for k in ("pos", "vel", "normal", "color", "mass", "restDensity", "type", "group", "uniqueId",
+                  "v_star", "pressure", "density", "force"):
+            if k in scene:
+                self.a[k][...] = np.asarray(scene[k]).reshape(self.a[k].shape)
+        if "uniqueId" not in scene:
+            self.a["uniqueId"][...] = np.arange(n, dtype=np.int32)
+
+    def close(self):
+        if self._s:
+            self.a = {}
+            self.orc._destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # stage calls ----------------------------------------------------
+    def calc_hash(self, p): self.orc._calc_hash(C.byref(p), self._s)
+    def sort_particle(self): self.orc._sort_particle(self._s)
+    def reorder(self, p): self.orc._reorder_data_and_find_cell_start(C.byref(p), self._s)
+    def copy_sorted_to_primary(self): self.orc._copy_sorted_to_primary(self._s)
+    def sort_particles(self, p): self.orc._sort_particles(C.byref(p), self._s)
+    def compute_pressure(self, p): self.orc._compute_pressure(C.byref(p), self._s)
+    def compute_force(self, p): self.orc._compute_force(C.byref(p), self._s)
+    def advect(self, p): self.orc._advect(C.byref(p), self._s)
+    def rigid_particle_volume(self, p): self.orc._rigid_particle_volume(C.byref(p), self._s)
+    def solve_sph(self, p, nsteps=1): self.orc._solve_sph(C.byref(p), self._s, int(nsteps))

@@ -1,0 +1,537 @@
+/*
+ * sph_oracle.c -- CPU restatement of the reference WCSPH step (see sph_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; parity unpinned (no reference fixtures exist).
+ *
+ * All file:line citations are relative to /root/reference/particle_solver.
+ * Every function keeps the reference's evaluation order and its float/double
+ * promotions; `R` marks a value the reference holds in a `float`.
+ */
+#include "sph_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef orc_real R;
+typedef ORC_NAME(params) params_t;
+typedef ORC_NAME(state) state_t;
+
+#ifdef ORC_REAL_IS_DOUBLE
+#define R_SQRT(x) sqrt(x)
+#define R_FLOOR(x) floor(x)
+#define R_POW(x, y) pow((x), (y))
+#define R_ROUND(x) round(x)
+#else
+#define R_SQRT(x) sqrtf(x)
+#define R_FLOOR(x) floorf(x)
+#define R_POW(x, y) powf((x), (y))
+#define R_ROUND(x) roundf(x)
+#endif
+
+static int g_threads = 1;
+
+void ORC_NAME(set_threads)(int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    g_threads = nthreads;
+}
+int ORC_NAME(get_threads)(void) { return g_threads; }
+
+/* ------------------------------------------------------------------ */
+/* allocation                                                          */
+/* ------------------------------------------------------------------ */
+
+static void *zalloc(size_t count, size_t size) {
+    void *p = calloc(count ? count : 1, size);
+    return p;
+}
+
+state_t *ORC_NAME(create)(int n, int num_cells) {
+    state_t *s = (state_t *)zalloc(1, sizeof(state_t));
+    if (!s) return NULL;
+    s->n = n;
+    s->num_cells = num_cells;
+    size_t N = (size_t)n;
+#define A3(f) s->f = (R *)zalloc(N * 3, sizeof(R))
+#define A4(f) s->f = (R *)zalloc(N * 4, sizeof(R))
+#define A1(f) s->f = (R *)zalloc(N, sizeof(R))
+#define AI(f) s->f = (int *)zalloc(N, sizeof(int))
+    A3(pos); A3(vel); A3(normal); A3(force); A3(v_star); A4(color);
+    A1(mass); A1(density); A1(pressure); A1(restDensity);
+    AI(type); AI(group); AI(uniqueId); AI(indexTable);
+    A3(sortedPos); A3(sortedVel); A3(sortedNormal); A3(sortedV_star); A4(sortedColor);
+    A1(sortedMass); A1(sortedRestDensity); A1(sorted_pressure);
+    AI(sortedType); AI(sortedGroup); AI(sortedUniqueId);
+    AI(particleHash); AI(particleIndex);
+#undef A3
+#undef A4
+#undef A1
+#undef AI
+    s->gridCellStart = (int *)zalloc((size_t)num_cells, sizeof(int));
+    s->gridCellEnd = (int *)zalloc((size_t)num_cells, sizeof(int));
+    return s;
+}
+
+void ORC_NAME(destroy)(state_t *s) {
+    if (!s) return;
+    free(s->pos); free(s->vel); free(s->normal); free(s->force); free(s->v_star); free(s->color);
+    free(s->mass); free(s->density); free(s->pressure); free(s->restDensity);
+    free(s->type); free(s->group); free(s->uniqueId); free(s->indexTable);
+    free(s->sortedPos); free(s->sortedVel); free(s->sortedNormal); free(s->sortedV_star);
+    free(s->sortedColor); free(s->sortedMass); free(s->sortedRestDensity); free(s->sorted_pressure);
+    free(s->sortedType); free(s->sortedGroup); free(s->sortedUniqueId);
+    free(s->particleHash); free(s->particleIndex); free(s->gridCellStart); free(s->gridCellEnd);
+    free(s);
+}
+
+/* ------------------------------------------------------------------ */
+/* derived parameters: MultiphaseSPHSolver::LoadParam,                 */
+/* solver/MultiphaseSPHSolver.cpp:452-469 (and ParseParam :381)        */
+/* ------------------------------------------------------------------ */
+
+void ORC_NAME(derive_params)(params_t *p, R spacing, R smoothratio, const R vmin[3], const R vmax[3]) {
+    p->spacing = spacing;
+    p->smoothradius = spacing * smoothratio; /* :381 */
+    p->dx = p->smoothradius;                 /* :452 */
+    for (int a = 0; a < 3; a++) {
+        p->gridxmin[a] = vmin[a];
+        p->gridxmax[a] = vmax[a];
+        p->gridres[a] = (int)R_ROUND((vmax[a] - vmin[a]) / p->dx); /* :453-455 */
+    }
+    R sr = p->smoothradius;
+    /* pow(float, float) is the float overload in C++; pow(float, int) promotes to double. */
+    p->kspikydiff = (R)(-45.0f / (3.141592 * (double)R_POW(sr, (R)6.0))); /* :466 */
+    p->kernel_cubic = (R)(1 / 3.141593 / pow((double)(sr / 2), 3.0));     /* :468 */
+    p->kernel_cubic_gradient = (R)(1.5 / (double)3.141593f / pow((double)(sr / 2), 4.0)); /* :469 */
+}
+
+/* ------------------------------------------------------------------ */
+/* cell coordinates and hash                                           */
+/* ------------------------------------------------------------------ */
+
+/* float -> int as cvt.rzi.s32.f32 does it on the reference's hardware:
+ * saturating, NaN -> 0 (plain C leaves out-of-range conversions undefined). */
+static inline int to_int_sat(R v) {
+    if (v != v) return 0;
+    if (v >= (R)2147483647.0) return 2147483647;
+    if (v <= (R)-2147483648.0) return (-2147483647 - 1);
+    return (int)v;
+}
+
+/* calcGridPos, solver/sph_kernel_impl.cuh:74-80 */
+static inline void calc_grid_pos(const params_t *p, const R *x, int g[3]) {
+    g[0] = to_int_sat(R_FLOOR((x[0] - p->gridxmin[0]) / p->dx));
+    g[1] = to_int_sat(R_FLOOR((x[1] - p->gridxmin[1]) / p->dx));
+    g[2] = to_int_sat(R_FLOOR((x[2] - p->gridxmin[2]) / p->dx));
+}
+
+/* calcGridHash, solver/sph_kernel_impl.cuh:58-72 (the :69 guard is unreachable
+ * after the range test but is kept). */
+static inline unsigned calc_grid_hash(const params_t *p, int cx, int cy, int cz) {
+    if (cx < 0 || cx >= p->gridres[0] || cy < 0 || cy >= p->gridres[1] || cz < 0 || cz >= p->gridres[2])
+        return ORC_GRID_UNDEF;
+    unsigned ret = (unsigned)(cy * p->gridres[0] * p->gridres[2] + cz * p->gridres[0] + cx);
+    if (ret > (unsigned)(p->gridres[0] * p->gridres[1] * p->gridres[2])) return ORC_GRID_UNDEF;
+    return ret;
+}
+
+/* calcHashD, solver/sph_kernel_impl.cuh:83-112; launcher sph_solver.cu:30-42.
+ * EPSILON is a double literal, so the domain test compares in double. */
+void ORC_NAME(calc_hash)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int i = 0; i < n; i++) {
+        const R *x = s->pos + 3 * (size_t)i;
+        unsigned hash;
+        if (!((double)x[0] < (double)p->gridxmax[0] - ORC_EPSILON &&
+              (double)x[0] > (double)p->gridxmin[0] + ORC_EPSILON &&
+              (double)x[1] < (double)p->gridxmax[1] - ORC_EPSILON &&
+              (double)x[1] > (double)p->gridxmin[1] + ORC_EPSILON &&
+              (double)x[2] < (double)p->gridxmax[2] - ORC_EPSILON &&
+              (double)x[2] > (double)p->gridxmin[2] + ORC_EPSILON)) {
+            hash = ORC_GRID_UNDEF;
+        } else {
+            int g[3];
+            calc_grid_pos(p, x, g);
+            hash = calc_grid_hash(p, g[0], g[1], g[2]);
+        }
+        s->particleHash[i] = (int)hash;
+        s->particleIndex[i] = i;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* sortParticle, solver/sph_solver.cu:46-53.                           */
+/* thrust::sort_by_key on int keys (Thrust of CUDA 9.2, not vendored in */
+/* the reference) is a stable least-significant-digit radix sort: the   */
+/* result is the ascending order of the keys with ties kept in their    */
+/* previous array order.  Restated as an 8-bit LSD radix sort whose     */
+/* per-thread chunks are taken in thread order, which keeps it stable.  */
+/* Keys are non-negative (cell ids and GRID_UNDEF).                     */
+/* ------------------------------------------------------------------ */
+
+void ORC_NAME(sort_particle)(state_t *s) {
+    const int n = s->n;
+    if (n <= 1) return;
+    int *k0 = s->particleHash, *v0 = s->particleIndex;
+    int *k1 = (int *)malloc((size_t)n * sizeof(int));
+    int *v1 = (int *)malloc((size_t)n * sizeof(int));
+    int T = g_threads;
+    if (T > n) T = 1;
+    size_t *hist = (size_t *)malloc((size_t)T * 256 * sizeof(size_t));
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        memset(hist, 0, (size_t)T * 256 * sizeof(size_t));
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            int t = omp_get_thread_num();
+#else
+            int t = 0;
+#endif
+            size_t lo = (size_t)n * t / T, hi = (size_t)n * (t + 1) / T;
+            size_t *h = hist + (size_t)t * 256;
+            for (size_t i = lo; i < hi; i++) h[((unsigned)k0[i] >> shift) & 255u]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                size_t sum = 0;
+                for (int d = 0; d < 256; d++)
+                    for (int tt = 0; tt < T; tt++) {
+                        size_t c = hist[(size_t)tt * 256 + d];
+                        hist[(size_t)tt * 256 + d] = sum;
+                        sum += c;
+                    }
+            }
+            for (size_t i = lo; i < hi; i++) {
+                size_t dst = h[((unsigned)k0[i] >> shift) & 255u]++;
+                k1[dst] = k0[i];
+                v1[dst] = v0[i];
+            }
+        }
+        int *tk = k0; k0 = k1; k1 = tk;
+        int *tv = v0; v0 = v1; v1 = tv;
+    }
+    /* four passes: the data is back in the caller's arrays */
+    free(k1);
+    free(v1);
+    free(hist);
+}
+
+/* ------------------------------------------------------------------ */
+/* reorderDataAndFindCellStartD, solver/sph_kernel_impl.cuh:116-200;   */
+/* launcher solver/sph_solver.cu:57-77 (memset of gridCellStart only:  */
+/* gridCellEnd keeps stale entries for empty cells).                   */
+/* ------------------------------------------------------------------ */
+
+void ORC_NAME(reorder_data_and_find_cell_start)(const params_t *p, state_t *s) {
+    (void)p;
+    const int n = s->n;
+    memset(s->gridCellStart, 0xff, (size_t)s->num_cells * sizeof(int));
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        unsigned hash = (unsigned)s->particleHash[index];
+        unsigned prev = index > 0 ? (unsigned)s->particleHash[index - 1] : 0u;
+        if (index == 0 || hash != prev) {
+            if (hash != ORC_GRID_UNDEF) s->gridCellStart[hash] = index;
+            if (index > 0) s->gridCellEnd[prev] = index;
+        }
+        if (index == n - 1) {
+            if (hash != ORC_GRID_UNDEF) s->gridCellEnd[hash] = index + 1;
+        }
+        size_t src = (size_t)s->particleIndex[index], dst = (size_t)index;
+        for (int a = 0; a < 3; a++) {
+            s->sortedPos[3 * dst + a] = s->pos[3 * src + a];
+            s->sortedVel[3 * dst + a] = s->vel[3 * src + a];
+            s->sortedNormal[3 * dst + a] = s->normal[3 * src + a];
+            s->sortedV_star[3 * dst + a] = s->v_star[3 * src + a];
+        }
+        for (int a = 0; a < 4; a++) s->sortedColor[4 * dst + a] = s->color[4 * src + a];
+        s->sortedMass[dst] = s->mass[src];
+        s->sortedType[dst] = s->type[src];
+        s->sortedGroup[dst] = s->group[src];
+        s->sortedUniqueId[dst] = s->uniqueId[src];
+        s->indexTable[s->sortedUniqueId[dst]] = index;
+        s->sortedRestDensity[dst] = s->restDensity[src];
+        s->sorted_pressure[dst] = s->pressure[src];
+    }
+}
+
+/* Note: `gridCellEnd[prev] = index` (:156-157) carries no GRID_UNDEF guard and
+ * needs none: GRID_UNDEF is the largest key, so a run boundary never has it on
+ * the `prev` side (this requires num_cells < GRID_UNDEF). */
+
+/* the 11 device-to-device copies that concern this path, solver/sph_solver.cpp:58-84 */
+void ORC_NAME(copy_sorted_to_primary)(state_t *s) {
+    size_t N = (size_t)s->n;
+    memcpy(s->pos, s->sortedPos, N * 3 * sizeof(R));
+    memcpy(s->vel, s->sortedVel, N * 3 * sizeof(R));
+    memcpy(s->normal, s->sortedNormal, N * 3 * sizeof(R));
+    memcpy(s->color, s->sortedColor, N * 4 * sizeof(R));
+    memcpy(s->type, s->sortedType, N * sizeof(int));
+    memcpy(s->group, s->sortedGroup, N * sizeof(int));
+    memcpy(s->mass, s->sortedMass, N * sizeof(R));
+    memcpy(s->uniqueId, s->sortedUniqueId, N * sizeof(int));
+    memcpy(s->v_star, s->sortedV_star, N * 3 * sizeof(R));
+    memcpy(s->restDensity, s->sortedRestDensity, N * sizeof(R));
+    memcpy(s->pressure, s->sorted_pressure, N * sizeof(R));
+}
+
+/* SPHSolver::SortParticles, solver/sph_solver.cpp:50-85 */
+void ORC_NAME(sort_particles)(const params_t *p, state_t *s) {
+    ORC_NAME(calc_hash)(p, s);
+    ORC_NAME(sort_particle)(s);
+    ORC_NAME(reorder_data_and_find_cell_start)(p, s);
+    ORC_NAME(copy_sorted_to_primary)(s);
+}
+
+/* ------------------------------------------------------------------ */
+/* smoothing kernel                                                    */
+/* ------------------------------------------------------------------ */
+
+/* Kernel_Cubic, solver/sph_kernel_impl.cuh:32-40.  q is a float; the two
+ * polynomial branches are evaluated in double because of their literals. */
+static inline R kernel_cubic(const params_t *p, R h, R x, R y, R z) {
+    R q = R_SQRT(x * x + y * y + z * z) / h;
+    R fq;
+    if (q >= 2) return 0;
+    if (q >= 1)
+        fq = (R)((double)((2 - q) * (2 - q) * (2 - q)) * 0.25);
+    else
+        fq = (R)((0.666667 - (double)(q * q) + 0.5 * (double)q * (double)q * (double)q) * 1.5);
+    return fq * p->kernel_cubic;
+}
+
+/* ------------------------------------------------------------------ */
+/* DensityCell + ComputePressureKernel,                                */
+/* solver/sph_kernel_impl.cuh:203-244, 246-266; launcher sph_solver.cu:80-88 */
+/* ------------------------------------------------------------------ */
+
+static inline void density_cell(const params_t *p, const state_t *s, int cx, int cy, int cz, int index,
+                                const R *pos, R *density) {
+    unsigned gridHash = calc_grid_hash(p, cx, cy, cz);
+    if (gridHash == ORC_GRID_UNDEF) return;
+    unsigned startIndex = (unsigned)s->gridCellStart[gridHash];
+    if (startIndex == 0xffffffffu) return;
+    unsigned endIndex = (unsigned)s->gridCellEnd[gridHash];
+    R sr = p->smoothradius;
+    R sr2 = sr * sr;
+    for (unsigned j = startIndex; j < endIndex; j++) {
+        const R *pos2 = s->pos + 3 * (size_t)j;
+        R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+        R d2 = xx * xx + xy * xy + xz * xz;
+        if (d2 >= sr2) continue;
+        R wij = kernel_cubic(p, (R)((double)sr * 0.5), xx, xy, xz);
+        if (s->type[j] == ORC_TYPE_FLUID) *density += s->mass[index] * wij;
+        if (s->type[j] == ORC_TYPE_RIGID) *density += s->restDensity[index] * s->restDensity[j] * wij;
+    }
+}
+
+void ORC_NAME(compute_pressure)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R density = 0;
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++)
+                    density_cell(p, s, g[0] + x, g[1] + y, g[2] + z, index, pos, &density);
+        s->density[index] = density;
+        R pr = p->pressureK * (R_POW(density / s->restDensity[index], (R)7) - 1);
+        if (pr < 0) pr = 0;
+        s->pressure[index] = pr;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* ForceCell + computeF,                                               */
+/* solver/sph_kernel_impl.cuh:269-355, 357-373; launcher sph_solver.cu:90-98 */
+/* ------------------------------------------------------------------ */
+
+static inline void force_cell(const params_t *p, const state_t *s, int cx, int cy, int cz, int index,
+                              const R *pos, R *force) {
+    unsigned gridHash = calc_grid_hash(p, cx, cy, cz);
+    if (gridHash == ORC_GRID_UNDEF) return;
+    unsigned startIndex = (unsigned)s->gridCellStart[gridHash];
+    R sr = p->smoothradius;
+    R sr2 = sr * sr;
+    if (startIndex == 0xffffffffu) return;
+    unsigned endIndex = (unsigned)s->gridCellEnd[gridHash];
+    const R *veli = s->vel + 3 * (size_t)index;
+
+    for (unsigned j = startIndex; j < endIndex; j++) {
+        const R *pos2 = s->pos + 3 * (size_t)j;
+        const R *velj = s->vel + 3 * (size_t)j;
+        R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+        R d2 = xx * xx + xy * xy + xz * xz;
+        R d = R_SQRT(d2);
+
+        if (j != (unsigned)index && s->type[j] == ORC_TYPE_FLUID) {
+            if (d2 >= sr2) continue;
+            R c = sr - d;
+            /* pressure, :291-294 */
+            R nablaw = p->kspikydiff * c * c / d;
+            R pc = nablaw * s->mass[j] *
+                   (s->pressure[j] / s->density[j] / s->density[j] +
+                    s->pressure[index] / s->density[index] / s->density[index]);
+            force[0] += xx * pc * (R)(-1);
+            force[1] += xy * pc * (R)(-1);
+            force[2] += xz * pc * (R)(-1);
+            /* viscosity, :297-299: `0.01 * sr2` makes the quotient and all that follows double */
+            R vc = (R)((double)(nablaw * d2) / ((double)d2 + 0.01 * (double)sr2) * (double)s->mass[j] /
+                       (double)s->density[j] * 2 * (double)p->viscosity);
+            force[0] += (veli[0] - velj[0]) * vc;
+            force[1] += (veli[1] - velj[1]) * vc;
+            force[2] += (veli[2] - velj[2]) * vc;
+        }
+
+        if (s->type[j] == ORC_TYPE_BOUNDARY) {
+            /* :316-339 */
+            R B = 1;
+            R q = d / sr;
+            if ((double)q < 0.66666)
+                B = (R)((double)B * 0.66666);
+            else if (q < 1)
+                B = (R)((double)B * ((double)(2 * q) - 1.5 * (double)q * (double)q));
+            else if (q < 2)
+                B = (R)((double)B * (0.5 * (double)(2 - q) * (double)(2 - q)));
+            else
+                B = 0;
+            B = (R)((double)B * (0.02 * 88.5 * 88.5 / (double)d));
+            R magnitude = s->mass[j] / (s->mass[index] + s->mass[j]) * B;
+            force[0] += xx * magnitude;
+            force[1] += xy * magnitude;
+            force[2] += xz * magnitude;
+            /* artificial viscosity, :342-350 */
+            R vx = veli[0] - velj[0], vy = veli[1] - velj[1], vz = veli[2] - velj[2];
+            R xv = vx * xx + vy * xy + vz * xz;
+            if (xv < 0) {
+                R c = sr - d;
+                R nablaw = p->kspikydiff * c * c / d;
+                R visc = (R)((double)(2 * p->boundary_visc * p->smoothradius) * 88.5 / 2000);
+                R pi = (R)((double)(-visc * xv) / ((double)d2 + 0.01 * (double)sr2));
+                force[0] += xx * pi * nablaw * s->mass[j] * (R)(-1);
+                force[1] += xy * pi * nablaw * s->mass[j] * (R)(-1);
+                force[2] += xz * pi * nablaw * s->mass[j] * (R)(-1);
+            }
+        }
+    }
+}
+
+void ORC_NAME(compute_force)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] != ORC_TYPE_FLUID) continue; /* force[index] keeps its old value */
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R force[3] = {0, 0, 0};
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++)
+                    force_cell(p, s, g[0] + x, g[1] + y, g[2] + z, index, pos, force);
+        /* :372 -- the literal (0,-9.8,0), not dParam.gravity */
+        s->force[3 * (size_t)index + 0] = force[0] + (R)0;
+        s->force[3 * (size_t)index + 1] = force[1] + (R)-9.8;
+        s->force[3 * (size_t)index + 2] = force[2] + (R)0;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* AdvectKernel, solver/sph_kernel_impl.cuh:377-391; launcher sph_solver.cu:100-108. */
+/* boundary_mode 1 adds the older snapshot's collision handling:       */
+/* advectAndCollision + clampBoundary,                                  */
+/* solver/新建文件夹/sph_kernel_impl.cuh:365-403 (skip TYPE_BOUNDARY,   */
+/* clamp to the grid box in the order y, x, z and zero that velocity    */
+/* component; `gridxmin + EPSILON` is a double rounded back to float).  */
+/* ------------------------------------------------------------------ */
+
+void ORC_NAME(advect)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        if (p->boundary_mode == ORC_BOUNDARY_LEGACY_CLAMP && s->type[index] == ORC_TYPE_BOUNDARY) continue;
+        R *vel = s->vel + 3 * (size_t)index;
+        R *pos = s->pos + 3 * (size_t)index;
+        const R *force = s->force + 3 * (size_t)index;
+        for (int a = 0; a < 3; a++) vel[a] += force[a] * p->dt;
+        for (int a = 0; a < 3; a++) pos[a] += vel[a] * p->dt;
+
+        R dr[3];
+        for (int a = 0; a < 3; a++) dr[a] = p->gravity[a] - force[a];
+        R magnitude = R_SQRT(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+        if (magnitude > p->acceleration_limit)
+            for (int a = 0; a < 3; a++) dr[a] = dr[a] / magnitude * p->acceleration_limit;
+        for (int a = 0; a < 3; a++) s->v_star[3 * (size_t)index + a] = p->gravity[a] - dr[a];
+
+        if (p->boundary_mode == ORC_BOUNDARY_LEGACY_CLAMP) {
+            static const int order[3] = {1, 0, 2};
+            for (int k = 0; k < 3; k++) {
+                int a = order[k];
+                if ((double)pos[a] < (double)p->gridxmin[a] + ORC_EPSILON) {
+                    pos[a] = (R)((double)p->gridxmin[a] + ORC_EPSILON);
+                    vel[a] = 0;
+                }
+                if ((double)pos[a] > (double)p->gridxmax[a] - ORC_EPSILON) {
+                    pos[a] = (R)((double)p->gridxmax[a] - ORC_EPSILON);
+                    vel[a] = 0;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* RigidParticleVolumeCell + RigidParticleVolumeKernel,                */
+/* solver/sph_kernel_impl.cuh:2423-2473: restDensity of a rigid        */
+/* particle = 1 / sum of W over rigid neighbours (itself included).    */
+/* ------------------------------------------------------------------ */
+
+void ORC_NAME(rigid_particle_volume)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    R sr = p->smoothradius;
+    R sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] != ORC_TYPE_RIGID) continue;
+        const R *xi = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, xi, g);
+        R sum_wij = 0;
+        for (int z = -1; z <= 1; z++)
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    unsigned h = calc_grid_hash(p, g[0] + x, g[1] + y, g[2] + z);
+                    if (h == ORC_GRID_UNDEF) continue;
+                    unsigned start = (unsigned)s->gridCellStart[h];
+                    if (start == 0xffffffffu) continue;
+                    unsigned end = (unsigned)s->gridCellEnd[h];
+                    for (unsigned j = start; j < end; j++) {
+                        if (s->type[j] != ORC_TYPE_RIGID) continue;
+                        const R *xj = s->pos + 3 * (size_t)j;
+                        R xx = xi[0] - xj[0], xy = xi[1] - xj[1], xz = xi[2] - xj[2];
+                        R d2 = xx * xx + xy * xy + xz * xz;
+                        if (d2 >= sr2) continue;
+                        sum_wij += kernel_cubic(p, sr / 2, xx, xy, xz);
+                    }
+                }
+        s->restDensity[index] = 1 / sum_wij;
+    }
+}
+
+/* SPHSolver::SolveSPH, solver/sph_solver.cpp:87-98 (host copy-back left out) */
+void ORC_NAME(solve_sph)(const params_t *p, state_t *s, int nsteps) {
+    for (int k = 0; k < nsteps; k++) {
+        ORC_NAME(sort_particles)(p, s);
+        ORC_NAME(compute_pressure)(p, s);
+        ORC_NAME(compute_force)(p, s);
+        ORC_NAME(advect)(p, s);
+    }
+}

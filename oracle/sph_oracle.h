@@ -1,0 +1,123 @@
+/*
+ * sph_oracle.h -- CPU restatement of the reference's WCSPH particle-solver step.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP path is compared with
+ * (and the timed "port" CPU baseline).  Nothing in the product links or calls
+ * it; the product fails loudly when its HIP library is missing.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ * for this path, and its sources need the CUDA toolkit headers, Thrust and
+ * MSVC extensions that this image does not have, so it cannot be compiled here
+ * without writing stand-ins for them.  The restatement below follows the
+ * reference text expression by expression (each function cites file:line under
+ * /root/reference/particle_solver) and is anchored only by the few known
+ * answers listed in tests/test_oracle_known_answers.py.
+ *
+ * Arithmetic conventions (what a C++ compiler does with the reference text):
+ *   - `float` variables, but unsuffixed literals (0.25, 0.666667, 1.5, 0.01,
+ *     0.02, 88.5, 0.66666, 9.8) promote the enclosing sub-expression to double;
+ *     every such promotion is written out with explicit casts here.
+ *   - sqrt/floor of a float resolve to the float overloads (sqrtf/floorf).
+ *   - no FMA contraction (built with -ffp-contract=off).
+ *
+ * Two builds of the same source: real = float (symbols orc_*), and
+ * -DORC_REAL_IS_DOUBLE, real = double (symbols orc64_*), in which every
+ * float of the reference is widened to double (the reference has no fp64
+ * path; that build only serves the fp64 GPU-vs-CPU check).
+ */
+#ifndef SPH_ORACLE_H
+#define SPH_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifdef ORC_REAL_IS_DOUBLE
+typedef double orc_real;
+#define ORC_NAME(x) orc64_##x
+#else
+typedef float orc_real;
+#define ORC_NAME(x) orc_##x
+#endif
+
+/* solver/particle_common.h:6-16 */
+#define ORC_TYPE_FLUID 0
+#define ORC_TYPE_CLOTH 1
+#define ORC_TYPE_BOUNDARY 2
+#define ORC_TYPE_EMITTER 3
+#define ORC_TYPE_RIGID 4
+#define ORC_TYPE_DEFORMABLE 5
+#define ORC_TYPE_GRANULAR 6
+
+/* solver/cuda_common.cuh:10-11 */
+#define ORC_EPSILON 1e-10
+#define ORC_GRID_UNDEF 99999999
+
+/* advect variants */
+#define ORC_BOUNDARY_VERBATIM 0      /* AdvectKernel, sph_kernel_impl.cuh:377-391 */
+#define ORC_BOUNDARY_LEGACY_CLAMP 1  /* + skip TYPE_BOUNDARY and clampBoundary,
+                                        solver/新建文件夹/sph_kernel_impl.cuh:365-403 */
+
+/* Hot-path fields of SimParam_SPH (solver/sph_solver.cuh:10-77). */
+typedef struct ORC_NAME(params) {
+    orc_real dx;
+    orc_real gridxmin[3];
+    orc_real gridxmax[3];
+    int gridres[3];
+    orc_real gravity[3];
+    orc_real dt;
+    orc_real viscosity;
+    orc_real spacing;
+    orc_real smoothradius;
+    orc_real kspikydiff;
+    orc_real kernel_cubic;
+    orc_real kernel_cubic_gradient;
+    orc_real pressureK;
+    orc_real boundary_visc;
+    orc_real acceleration_limit;
+    int boundary_mode;
+} ORC_NAME(params);
+
+/* Hot-path subset of SimData_SPH (solver/sph_solver.cuh:79-190): tight AoS
+ * arrays, 3 reals per cfloat3, 4 per cfloat4, exactly as the reference. */
+typedef struct ORC_NAME(state) {
+    int n;
+    int num_cells;
+    orc_real *pos, *vel, *normal, *force, *v_star; /* n x 3 */
+    orc_real *color;                                /* n x 4 */
+    orc_real *mass, *density, *pressure, *restDensity;
+    int *type, *group, *uniqueId, *indexTable;
+    orc_real *sortedPos, *sortedVel, *sortedNormal, *sortedV_star;
+    orc_real *sortedColor;
+    orc_real *sortedMass, *sortedRestDensity, *sorted_pressure;
+    int *sortedType, *sortedGroup, *sortedUniqueId;
+    int *particleHash, *particleIndex, *gridCellStart, *gridCellEnd;
+} ORC_NAME(state);
+
+ORC_NAME(state) *ORC_NAME(create)(int n, int num_cells);
+void ORC_NAME(destroy)(ORC_NAME(state) *s);
+
+/* MultiphaseSPHSolver::LoadParam derived constants, MultiphaseSPHSolver.cpp:452-469 */
+void ORC_NAME(derive_params)(ORC_NAME(params) *p, orc_real spacing, orc_real smoothratio,
+                             const orc_real vmin[3], const orc_real vmax[3]);
+
+void ORC_NAME(set_threads)(int nthreads);
+int ORC_NAME(get_threads)(void);
+
+/* the operator seam, solver/sph_solver.cuh:197-220 */
+void ORC_NAME(calc_hash)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(sort_particle)(ORC_NAME(state) *s);
+void ORC_NAME(reorder_data_and_find_cell_start)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(copy_sorted_to_primary)(ORC_NAME(state) *s); /* sph_solver.cpp:58-84 */
+void ORC_NAME(sort_particles)(const ORC_NAME(params) *p, ORC_NAME(state) *s); /* SPHSolver::SortParticles */
+void ORC_NAME(compute_pressure)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(compute_force)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(advect)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(rigid_particle_volume)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+/* SPHSolver::SolveSPH without the D2H copy, sph_solver.cpp:87-98 */
+void ORC_NAME(solve_sph)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int nsteps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

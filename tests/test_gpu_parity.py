@@ -1,0 +1,247 @@
+"""GPU parity: every stage of the HIP path, called through the C ABI, against the CPU oracle on the
+same inputs.  Integer outputs (cell hash, sorted order, cell ranges, index table) must be bit-exact;
+floating-point outputs must agree within 1e-5 relative (fp32) as the tolerance written in each test.
+"""
+import numpy as np
+import pytest
+
+from fluidsolver_amd import scenes
+from tests.util import gpu_solver, oracle_pair, rel_err, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # fp32 relative tolerance for density / force / position
+
+
+def small_dam(seed=12345, walls=True, mode=1):
+    sc = scenes.dam_break(14, 12, 10, tank_x_factor=2.0, walls=walls, boundary_mode=mode)
+    return scenes.jittered(sc, seed=seed, pos_jitter=0.2, vel_scale=1.0)
+
+
+def edge_scene():
+    """particles on / outside the grid box, an over-full cell, empty cells, coincident pair"""
+    sc = scenes.dam_break(6, 6, 6, tank_x_factor=2.0, walls=False, boundary_mode=0)
+    P = sc["params"]
+    lo, hi = np.array(P["vmin"], np.float32), np.array(P["vmax"], np.float32)
+    rng = np.random.Generator(np.random.PCG64(7))
+    extra = [
+        lo.copy(), hi.copy(),                                  # exactly on the box corners
+        np.array([lo[0], 0.01, 0.01], np.float32),             # on a face
+        np.array([hi[0], 0.01, 0.01], np.float32),
+        np.nextafter(hi, lo).astype(np.float32),               # just inside the far corner
+        np.nextafter(lo, hi).astype(np.float32),
+        lo - 0.5, hi + 0.5, np.array([0.01, -5.0, 0.01], np.float32),   # outside
+        np.array([0.011, 0.012, 0.013], np.float32), np.array([0.011, 0.012, 0.013], np.float32),  # coincident
+    ]
+    crowd = (np.array([0.031, 0.031, 0.031], np.float32) +
+             rng.uniform(0, 0.008, (100, 3)).astype(np.float32))        # > 64 particles in one cell
+    add = np.concatenate([np.stack(extra), crowd]).astype(np.float32)
+    m = len(add)
+    out = {}
+    for k, v in sc.items():
+        if k in ("params", "n_fluid"):
+            out[k] = v
+    n0 = len(sc["pos"])
+    out["pos"] = np.concatenate([sc["pos"], add])
+    out["vel"] = np.concatenate([sc["vel"], rng.uniform(-1, 1, (m, 3)).astype(np.float32)])
+    out["normal"] = np.concatenate([sc["normal"], np.zeros((m, 3), np.float32)])
+    out["color"] = np.concatenate([sc["color"], np.ones((m, 4), np.float32)])
+    out["type"] = np.concatenate([sc["type"], np.zeros(m, np.int32)])
+    out["group"] = np.concatenate([sc["group"], np.full(m, 3, np.int32)])
+    out["mass"] = np.concatenate([sc["mass"], np.full(m, sc["mass"][0], np.float32)])
+    out["restDensity"] = np.concatenate([sc["restDensity"], np.full(m, 1000, np.float32)])
+    # a shuffled (but valid) uniqueId permutation
+    out["uniqueId"] = rng.permutation(n0 + m).astype(np.int32)
+    # shuffle the upload order so that ties inside cells are not already sorted
+    perm = rng.permutation(n0 + m)
+    for k in ("pos", "vel", "normal", "color", "type", "group", "mass", "restDensity", "uniqueId"):
+        out[k] = np.ascontiguousarray(out[k][perm])
+    return out
+
+
+SCENES = {
+    "small_dam_walls": lambda: small_dam(),
+    "small_dam_verbatim": lambda: small_dam(seed=99, walls=True, mode=0),
+    "edge": edge_scene,
+}
+
+
+@pytest.fixture(params=sorted(SCENES))
+def pair(request, orc32):
+    sc = SCENES[request.param]()
+    p_o, st = oracle_pair(orc32, sc)
+    p_g, s = gpu_solver(sc)
+    yield sc, p_o, st, p_g, s
+    s.close()
+    st.close()
+
+
+def check_sorted_state(s, st):
+    for k in ("pos", "vel", "mass", "restDensity", "color", "normal"):
+        assert np.array_equal(s.get(k).view(np.int32), st[k].view(np.int32)), k
+    for k in ("type", "group", "uniqueId", "indexTable"):
+        assert np.array_equal(s.get(k), st[k]), k
+
+
+def test_hash_sort_reorder_bit_exact(pair):
+    sc, p_o, st, p_g, s = pair
+    assert list(p_g.gridres) == list(p_o.gridres)
+    # calcHash
+    st.calc_hash(p_o)
+    s.calc_hash()
+    assert np.array_equal(s.get("particleHash"), st["particleHash"])
+    assert np.array_equal(s.get("particleIndex"), st["particleIndex"])
+    # sortParticle
+    st.sort_particle()
+    s.sort_particle()
+    assert np.array_equal(s.get("particleHash"), st["particleHash"])
+    assert np.array_equal(s.get("particleIndex"), st["particleIndex"])
+    # reorderDataAndFindCellStart (+ the sorted->primary copies)
+    st.reorder(p_o)
+    st.copy_sorted_to_primary()
+    s.reorder()
+    check_sorted_state(s, st)
+    gs, ge = s.get("gridCellStart"), s.get("gridCellEnd")
+    assert np.array_equal(gs, st["gridCellStart"])
+    live = st["gridCellStart"] != -1
+    assert np.array_equal(ge[live], st["gridCellEnd"][live])
+    n_undef = int((st["particleHash"] == scenes_undef()).sum())
+    assert s.num_undef() == n_undef
+
+
+def scenes_undef():
+    return 99999999
+
+
+def test_density_pressure(pair):
+    sc, p_o, st, p_g, s = pair
+    st.sort_particles(p_o)
+    s.sort_particles()
+    st.compute_pressure(p_o)
+    s.compute_pressure()
+    d_g, d_o = s.get("density"), st["density"]
+    assert rel_err(d_g, d_o) <= TOL
+    # same operation order and correctly rounded sqrt/div: the sums should match to the last bit
+    assert ulp_diff(d_g, d_o) <= 2
+    pr_g, pr_o = s.get("pressure"), st["pressure"]
+    ok = np.isfinite(pr_o)
+    assert np.array_equal(np.isfinite(pr_g), ok)
+    assert rel_err(pr_g[ok], pr_o[ok]) <= TOL
+
+
+def test_force_from_same_state(pair):
+    sc, p_o, st, p_g, s = pair
+    st.sort_particles(p_o)
+    s.sort_particles()
+    st.compute_pressure(p_o)
+    s.compute_pressure()
+    # identical inputs for the force pass
+    s.set("density", st["density"])
+    s.set("pressure", st["pressure"])
+    st.compute_force(p_o)
+    s.compute_force()
+    f_g, f_o = s.get("force"), st["force"]
+    ok = np.isfinite(f_o).all(axis=1)
+    assert np.array_equal(np.isfinite(f_g).all(axis=1), ok)
+    assert ok.sum() > 0.9 * len(ok)
+    assert rel_err(f_g[ok], f_o[ok]) <= TOL
+
+
+def test_advect_from_same_state(pair):
+    sc, p_o, st, p_g, s = pair
+    st.sort_particles(p_o)
+    s.sort_particles()
+    st.compute_pressure(p_o)
+    st.compute_force(p_o)
+    f = np.nan_to_num(st["force"], nan=0.0, posinf=0.0, neginf=0.0)
+    st["force"][...] = f
+    s.set("force", f)
+    st.advect(p_o)
+    s.advect()
+    for k in ("pos", "vel", "v_star"):
+        assert np.array_equal(s.get(k).view(np.int32), st[k].view(np.int32)), k
+
+
+def test_full_steps_track_oracle(orc32):
+    """20 x SolveSPH on the GPU and on the oracle from the same start.  Particles are matched by
+    uniqueId; positions must agree within 1e-5 of the domain size, the particle set per cell too
+    (checked through the sorted hash of the last step for all but borderline particles)."""
+    sc = scenes.jittered(scenes.dam_break(14, 12, 10, tank_x_factor=2.0), seed=5, pos_jitter=0.02, vel_scale=0.02)
+    p_o, st = oracle_pair(orc32, sc)
+    p_g, s = gpu_solver(sc)
+    steps = 20
+    st.solve_sph(p_o, steps)
+    s.step(steps)
+    s.synchronize()
+    uid_g, uid_o = s.get("uniqueId"), st["uniqueId"]
+    pos_g = np.empty_like(st["pos"]); pos_g[uid_g] = s.get("pos")
+    pos_o = np.empty_like(st["pos"]); pos_o[uid_o] = st["pos"]
+    vel_g = np.empty_like(st["vel"]); vel_g[uid_g] = s.get("vel")
+    vel_o = np.empty_like(st["vel"]); vel_o[uid_o] = st["vel"]
+    scale = float(np.abs(np.array(sc["params"]["vmax"]) - np.array(sc["params"]["vmin"])).max())
+    assert np.abs(pos_g.astype(np.float64) - pos_o).max() <= TOL * scale
+    assert rel_err(vel_g, vel_o) <= 1e-3   # velocities amplify rounding differences over 20 steps
+    same_order = (uid_g == uid_o).mean()
+    assert same_order > 0.99
+    s.close(); st.close()
+
+
+def test_rigid_particle_volume_and_reference_scene(orc32):
+    """The shipped scene (52 272 fluid + OpenBox of TYPE_RIGID particles): RigidParticleVolume, then
+    density with the rigid branch, force and advect."""
+    sc = scenes.reference_scene(with_boundary=True)
+    sc = scenes.jittered(sc, seed=3, pos_jitter=0.05, vel_scale=0.1)
+    p_o, st = oracle_pair(orc32, sc)
+    p_g, s = gpu_solver(sc)
+    st.sort_particles(p_o); s.sort_particles()
+    check_sorted_state(s, st)
+    st.rigid_particle_volume(p_o); s.rigid_particle_volume()
+    rd_g, rd_o = s.get("restDensity"), st["restDensity"]
+    assert ulp_diff(rd_g, rd_o) <= 2
+    s.set("restDensity", rd_o)
+    st.compute_pressure(p_o); s.compute_pressure()
+    fluid = st["type"] == 0
+    assert (st["type"] == 4).sum() > 10000
+    assert rel_err(s.get("density")[fluid], st["density"][fluid]) <= TOL
+    s.set("density", st["density"]); s.set("pressure", st["pressure"])
+    st.compute_force(p_o); s.compute_force()
+    assert rel_err(s.get("force")[fluid], st["force"][fluid]) <= TOL
+    s.set("force", st["force"])
+    st.advect(p_o); s.advect()
+    assert np.array_equal(s.get("pos").view(np.int32), st["pos"].view(np.int32))
+    pos, col = s.readback_pos_color()
+    assert np.array_equal(pos.view(np.int32), st["pos"].view(np.int32))
+    assert np.array_equal(col.view(np.int32), st["color"].view(np.int32))
+    s.close(); st.close()
+
+
+def test_empty_and_single(orc32):
+    sc = scenes.dam_break(2, 2, 2, walls=False, boundary_mode=0)
+    for n in (0, 1):
+        sub = {k: (v[:n] if k not in ("params", "n_fluid") else v) for k, v in sc.items()}
+        sub["uniqueId"] = np.arange(n, dtype=np.int32)
+        p_o, st = oracle_pair(orc32, sub)
+        p_g, s = gpu_solver(sub, capacity=4)
+        st.solve_sph(p_o, 2)
+        s.step(2)
+        s.synchronize()
+        assert s.n == n
+        assert np.array_equal(s.get("pos").view(np.int32), st["pos"].view(np.int32))
+        s.close(); st.close()
+
+
+def test_call_order_errors():
+    from fluidsolver_amd import capi
+    sc = small_dam()
+    p_g, s = gpu_solver(sc)
+    with pytest.raises(capi.FsaError):
+        s.compute_pressure()          # no sort yet
+    with pytest.raises(capi.FsaError):
+        s.sort_particle()             # no hash yet
+    with pytest.raises((capi.FsaError, KeyError)):
+        s.get("nonsense")
+    bad = dict(sc)
+    bad["uniqueId"] = np.zeros(len(sc["pos"]), np.int32)
+    with pytest.raises(capi.FsaError):
+        s.upload(bad)                 # not a permutation
+    s.close()
