@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-steps/s of the WCSPH step on the 16M-particle dam break.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one SPHSolver::SolveSPH pass (cell hash -> stable counting sort -> reorder -> density /
+pressure -> force -> integration) over all particles, device resident, no host read-back inside
+the timed region.  Rank 0 prints ONE JSON line.  For N > 1 the driver launches one process per GPU
+with torch.distributed.run; the grid is cut into z-slabs (fluidsolver_amd/slabs.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+# algorithmic bytes per particle and launch (fp32, minimal SoA hot set)
+ALGO_BYTES = {
+    "hash_count": 20,   # R pos 12, W hash 4 + slot 4
+    "scatter": 12,      # R hash 4 + slot 4, W index 4
+    "rank": 12,
+    "reorder": 88,      # R perm 4 + gather 40, W 40 + index table 4
+    "density": 32,      # R pos 12 + type 4 + mass 4 + restDensity 4, W density 4 + pressure 4
+    "force": 52,        # R pos 12 + vel 12 + type 4 + mass 4 + density 4 + pressure 4, W force 12
+    "advect": 76,       # R force 12 + vel 12 + pos 12 + type 4, W vel 12 + pos 12 + v_star 12
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spinup", type=int, default=int(os.environ.get("FSA_BENCH_SPINUP", 100)),
+                    help="untimed steps before warm-up so that the dam has started to collapse")
+    ap.add_argument("--scene", default=os.environ.get("FSA_BENCH_SCENE", "dam16m"),
+                    choices=["dam16m", "dam1m", "dam128k"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=None)
+    return ap.parse_args()
+
+
+SCENES = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64)}
+
+
+def build_scene(name):
+    from fluidsolver_amd import scenes
+    nx, ny, nz = SCENES[name]
+    return scenes.dam_break(nx, ny, nz)
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The CPU oracle (a port of the reference step, OpenMP over particles) timed on this host on a
+    bounded sample: the 1M-particle dam break of the same construction."""
+    from oracle.orc import Oracle
+    from fluidsolver_amd import scenes
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    orc = Oracle("f32")
+    orc.set_threads(threads)
+    sc = scenes.dam_break(128, 64, 128)
+    P = sc["params"]
+    p = orc.make_params(P["spacing"], P["smoothratio"], P["vmin"], P["vmax"], gravity=P["gravity"], dt=P["dt"],
+                        viscosity=P["viscosity"], pressureK=P["pressureK"], boundary_visc=P["boundary_visc"],
+                        acceleration_limit=P["acceleration_limit"], boundary_mode=P["boundary_mode"])
+    n = len(sc["pos"])
+    st = orc.new_state(n, p.gridres[0] * p.gridres[1] * p.gridres[2])
+    st.load(sc)
+    st.solve_sph(p, 1)  # first touch
+    t0 = time.perf_counter()
+    st.solve_sph(p, 1)
+    one = time.perf_counter() - t0
+    steps = max(2, min(200, int(seconds_target / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    st.solve_sph(p, steps)
+    dt = time.perf_counter() - t0
+    st.close()
+    return {"value": sc["n_fluid"] * steps / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/sph_oracle.c, 1M-particle dam break ({n} particles incl. walls, "
+                      f"{sc['n_fluid']} fluid counted), {steps} steps, {dt:.1f} s"}
+
+
+def run_single(args):
+    import torch
+    from fluidsolver_amd import capi
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(0)
+    sc = build_scene(args.scene)
+    n, n_fluid = len(sc["pos"]), sc["n_fluid"]
+    p = capi.make_params(capi.PRECISION_F32, **sc["params"])
+    s = capi.Solver(p, n)
+    if args.variant is not None:
+        s.set_variant(args.variant)
+    s.upload(sc)
+    s.step(args.spinup)
+    s.step(args.warmup)
+    s.synchronize()
+    s.timing_enable(True)
+    s.timing_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.step(args.steps)
+    s.synchronize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kt = s.timing_read()
+    s.timing_enable(False)
+    n_undef = s.num_undef() if args.steps + args.warmup + args.spinup > 0 else 0
+    s.close()
+    return dict(n=n, n_fluid=n_fluid, wall=wall, kernels=kt, num_cells=p.num_cells, n_undef=n_undef,
+                gridres=list(p.gridres))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from fluidsolver_amd import slabs
+        res = slabs.bench_distributed(args, build_scene)
+    else:
+        res = run_single(args)
+    if rank != 0:
+        return
+    wall, steps = res["wall"], args.steps
+    value = res["n_fluid"] * steps / wall
+    kernels = {k: {"launches": c, "avg_ms": (ms / c if c else 0.0)} for k, (c, ms) in res["kernels"].items()}
+    # the dominant kernel of the step
+    dom = max((k for k in kernels if k in ALGO_BYTES), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"],
+              default=None)
+    roof = None
+    if dom:
+        units = res["n_fluid"] if dom == "force" else res["n"]
+        units = units / max(1, args.gpus)
+        byts = ALGO_BYTES[dom] * units
+        avg_s = kernels[dom]["avg_ms"] * 1e-3
+        achieved = byts / avg_s / 1e9 if avg_s > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": byts, "avg_launch_ms": kernels[dom]["avg_ms"]}
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                t = json.load(open(prof))
+                key = f"{args.scene}:{dom}"
+                if key in t:
+                    roof["traffic"] = t[key]
+            except Exception:
+                pass
+    out = {
+        "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus,
+        "steps": steps, "warmup": args.warmup, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {"dam16m": "dam break, 256^3 = 16 777 216 fluid particles + one layer of wall "
+                                          "particles, WCSPH fp32, shipped SceneId-2 parameters (viscosity 0.01)",
+                                "dam1m": "dam break 128x64x128 = 1 048 576 fluid particles",
+                                "dam128k": "dam break 64x32x64 fluid particles"}[args.scene],
+                   "particles_total": res["n"], "particles_counted": res["n_fluid"], "grid": res["gridres"],
+                   "spinup_steps": args.spinup, "parallelism": f"z-slabs x{args.gpus}" if args.gpus > 1 else "1 GPU",
+                   "out_of_grid_particles": res["n_undef"]},
+        "roofline": roof, "kernels": kernels,
+    }
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -345,6 +345,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     s->n = n;
     s->cur = 0;
     invalidate_order(s);
+    s->count_valid = false;
     if (n == 0) return FSA_OK;
 
     Staging sp, sv, st, sm;
@@ -398,7 +399,7 @@ int fsa_num_undef(fsa_solver *hs, int *n) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
     if (!n) return fail(FSA_ERR_INVALID, "n is NULL");
-    if (!s->perm_valid && !s->sorted_valid) return fail(FSA_ERR_INVALID, "no sort has run on the current state");
+    if (!s->count_valid) return fail(FSA_ERR_INVALID, "no sort has run since the last upload");
     int in_grid = 0;
     FSA_HIP(hipStreamSynchronize(s->stream));
     FSA_HIP(hipMemcpy(&in_grid, s->b.cellStart + s->num_cells, sizeof(int), hipMemcpyDeviceToHost));
@@ -426,6 +427,7 @@ int fsa_sort_particle(fsa_solver *hs) {
     TRY(launch_scatter(s));
     TRY(launch_rank(s));
     s->perm_valid = true;
+    s->count_valid = true;
     return FSA_OK;
 }
 

@@ -71,6 +71,7 @@ struct Solver {
     bool perm_valid = false;    // sortedIndex/sortedHash/cellStart computed from hash
     bool sorted_valid = false;  // current arrays are in sorted order and cellStart matches them
     bool index_table_valid = false;
+    bool count_valid = false;   // cellStart[num_cells] holds the in-grid count of the last sort
     bool ref_cells_valid = false;
     int variant = 1;
     // timing
