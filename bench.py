@@ -45,6 +45,8 @@ def parse():
                     help="untimed steps before warm-up so that the dam has started to collapse")
     ap.add_argument("--scene", default=os.environ.get("FSA_BENCH_SCENE", "dam16m"),
                     choices=["dam16m", "dam1m", "dam128k"])
+    ap.add_argument("--jitter", type=float, default=float(os.environ.get("FSA_BENCH_JITTER", 0.0)),
+                    help="uniform position noise in units of the particle spacing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None)
     return ap.parse_args()
@@ -53,10 +55,15 @@ def parse():
 SCENES = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64)}
 
 
-def build_scene(name):
+def build_scene(name, jitter=0.0):
     from fluidsolver_amd import scenes
     nx, ny, nz = SCENES[name]
-    return scenes.dam_break(nx, ny, nz)
+    sc = scenes.dam_break(nx, ny, nz)
+    if jitter > 0:
+        n_fluid = sc["n_fluid"]
+        sc = scenes.jittered(sc, seed=2024, pos_jitter=jitter, vel_scale=0.0, fluid_only=True)
+        sc["n_fluid"] = n_fluid
+    return sc
 
 
 def cpu_baseline(seconds_target=12.0):
@@ -96,7 +103,7 @@ def run_single(args):
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(0)
-    sc = build_scene(args.scene)
+    sc = build_scene(args.scene, args.jitter)
     n, n_fluid = len(sc["pos"]), sc["n_fluid"]
     p = capi.make_params(capi.PRECISION_F32, **sc["params"])
     s = capi.Solver(p, n)

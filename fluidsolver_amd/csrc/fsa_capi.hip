@@ -102,7 +102,7 @@ static int check_params(const fsa_params *p) {
 static void free_all(Solver *s) {
     Buffers &b = s->b;
     void *ptrs[] = {b.posType[0], b.posType[1], b.velMass[0], b.velMass[1], b.restDensity[0], b.restDensity[1],
-                    b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.hash, b.slot,
+                    b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.pd, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable};
@@ -256,6 +256,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.pressure, N * R, true);  // MultiphaseSPHSolver.cpp:975 does clear this one
     ALLOC(b.force, N * 3 * R, true);
     ALLOC(b.v_star, N * 3 * R, true);
+    ALLOC(b.pd, N * 2 * R, true);
     ALLOC(b.hash, N * sizeof(int), true);
     ALLOC(b.slot, N * sizeof(int), true);
     ALLOC(b.tmpIndex, N * sizeof(int), true);

@@ -27,6 +27,7 @@ struct Buffers {
     void *pressure = nullptr;
     void *force = nullptr;   // tight 3-vectors
     void *v_star = nullptr;  // tight 3-vectors
+    void *pd = nullptr;      // {pressure / density^2, density} pairs for the tuned force pass
     // neighbour search
     int *hash = nullptr;         // cell of particle i (device order before the sort)
     int *slot = nullptr;         // arrival slot inside its cell / rank among out-of-grid particles of its block
@@ -114,6 +115,8 @@ int launch_density(Solver *s);
 int launch_force(Solver *s);
 int launch_advect(Solver *s);
 int launch_rigid_volume(Solver *s);
+int launch_density_tuned(Solver *s);
+int launch_force_tuned(Solver *s);
 int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
 int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);
 int launch_unpack_w(Solver *s, const void *src4, void *dst, int n, bool as_int);

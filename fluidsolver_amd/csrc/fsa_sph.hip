@@ -11,33 +11,13 @@
 // row are adjacent in the sorted arrays: the walk below visits 9 contiguous index ranges
 // [cellStart[row + xlo], cellStart[row + xhi + 1]) and thereby meets the neighbours in exactly the
 // reference's order (the per-particle sums are accumulated in that order).
+#include "fsa_pair.h"
 #include "fsa_solver.h"
 
 namespace fsa {
 
-template <typename T> struct RowWalk {
-    int cx, cy, cz, xlo, xhi;
-    bool any;
-    __device__ __forceinline__ RowWalk(const DevParams<T> &P, T x, T y, T z) {
-        calc_grid_pos(P, x, y, z, cx, cy, cz);
-        xlo = max(cx - 1, 0);
-        xhi = min(cx + 1, P.gres[0] - 1);
-        any = xlo <= xhi;
-    }
-    // index range of row (cy + dy, cz + dz); false when the row lies outside the held grid
-    __device__ __forceinline__ bool row(const DevParams<T> &P, const int *__restrict__ cellStart, int dy, int dz,
-                                        int &start, int &end) const {
-        const int y = cy + dy, z = cz + dz, lz = z - P.z0;
-        if (!any || y < 0 || y >= P.gres[1] || z < 0 || z >= P.gres[2] || lz < 0 || lz >= P.nz) return false;
-        const int base = (y * P.nz + lz) * P.gres[0];
-        start = cellStart[base + xlo];
-        end = cellStart[base + xhi + 1];
-        return true;
-    }
-};
-
 // ------------------------------------------------------------------------------------------------
-// density + Tait equation of state
+// density + Tait equation of state (ComputePressureKernel, solver/sph_kernel_impl.cuh:246-266)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void density_kernel(DevParams<T> P, int n,
@@ -49,27 +29,8 @@ __global__ __launch_bounds__(kBlock) void density_kernel(DevParams<T> P, int n,
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index >= n) return;
     const Vec4<T> pi = posType[index];
-    const T mass_i = velMass[index].w;
     const T rd_i = restDensity[index];
-    const T sr = P.sr, sr2 = sr * sr;
-    const T h = (T)((double)sr * 0.5);
-    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
-    T dens = 0;
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++) {
-            int start, end;
-            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
-            for (int j = start; j < end; j++) {
-                const Vec4<T> pj = posType[j];
-                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-                const T d2 = xx * xx + xy * xy + xz * xz;
-                if (d2 >= sr2) continue;
-                const T wij = kernel_cubic(P, h, xx, xy, xz);
-                const int tj = unpack_int(pj.w);
-                if (tj == FSA_TYPE_FLUID) dens += mass_i * wij;
-                if (tj == FSA_TYPE_RIGID) dens += rd_i * restDensity[j] * wij;
-            }
-        }
+    const T dens = density_walk_global(P, index, pi, velMass[index].w, rd_i, posType, restDensity, cellStart);
     density[index] = dens;
     T pr = P.pressureK * (r_pow(dens / rd_i, (T)7) - 1);
     if (pr < 0) pr = 0;
@@ -77,7 +38,7 @@ __global__ __launch_bounds__(kBlock) void density_kernel(DevParams<T> P, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// force
+// force (computeF, solver/sph_kernel_impl.cuh:357-373)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void force_kernel(DevParams<T> P, int n, const Vec4<T> *__restrict__ posType,
@@ -88,76 +49,18 @@ __global__ __launch_bounds__(kBlock) void force_kernel(DevParams<T> P, int n, co
                                                        Vec3<T> *__restrict__ force) {
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index >= n) return;
-    const Vec4<T> pi = posType[index];
-    if (unpack_int(pi.w) != FSA_TYPE_FLUID) return;  // force[index] keeps its old value
-    const Vec4<T> vi = velMass[index];
-    const T mass_i = vi.w;
-    const T dens_i = density[index], pres_i = pressure[index];
-    const T sr = P.sr, sr2 = sr * sr;
-    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
-    T fx = 0, fy = 0, fz = 0;
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++) {
-            int start, end;
-            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
-            for (int j = start; j < end; j++) {
-                const Vec4<T> pj = posType[j];
-                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-                const T d2 = xx * xx + xy * xy + xz * xz;
-                const T d = r_sqrt(d2);
-                const int tj = unpack_int(pj.w);
-                if (j != index && tj == FSA_TYPE_FLUID) {
-                    if (d2 >= sr2) continue;
-                    const Vec4<T> vj = velMass[j];
-                    const T mass_j = vj.w, dens_j = density[j], pres_j = pressure[j];
-                    const T c = sr - d;
-                    const T nablaw = P.kspikydiff * c * c / d;
-                    const T pc = nablaw * mass_j * (pres_j / dens_j / dens_j + pres_i / dens_i / dens_i);
-                    fx += xx * pc * (T)(-1);
-                    fy += xy * pc * (T)(-1);
-                    fz += xz * pc * (T)(-1);
-                    const T vc = (T)((double)(nablaw * d2) / ((double)d2 + 0.01 * (double)sr2) * (double)mass_j /
-                                     (double)dens_j * 2 * (double)P.viscosity);
-                    fx += (vi.x - vj.x) * vc;
-                    fy += (vi.y - vj.y) * vc;
-                    fz += (vi.z - vj.z) * vc;
-                }
-                if (tj == FSA_TYPE_BOUNDARY) {
-                    const Vec4<T> vj = velMass[j];
-                    const T mass_j = vj.w;
-                    T B = 1;
-                    const T q = d / sr;
-                    if ((double)q < 0.66666)
-                        B = (T)((double)B * 0.66666);
-                    else if (q < 1)
-                        B = (T)((double)B * ((double)(2 * q) - 1.5 * (double)q * (double)q));
-                    else if (q < 2)
-                        B = (T)((double)B * (0.5 * (double)(2 - q) * (double)(2 - q)));
-                    else
-                        B = 0;
-                    B = (T)((double)B * (0.02 * 88.5 * 88.5 / (double)d));
-                    const T magnitude = mass_j / (mass_i + mass_j) * B;
-                    fx += xx * magnitude;
-                    fy += xy * magnitude;
-                    fz += xz * magnitude;
-                    const T vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
-                    const T xv = vx * xx + vy * xy + vz * xz;
-                    if (xv < 0) {
-                        const T c = sr - d;
-                        const T nablaw = P.kspikydiff * c * c / d;
-                        const T visc = (T)((double)(2 * P.boundary_visc * P.sr) * 88.5 / 2000);
-                        const T pi_ = (T)((double)(-visc * xv) / ((double)d2 + 0.01 * (double)sr2));
-                        fx += xx * pi_ * nablaw * mass_j * (T)(-1);
-                        fy += xy * pi_ * nablaw * mass_j * (T)(-1);
-                        fz += xz * pi_ * nablaw * mass_j * (T)(-1);
-                    }
-                }
-            }
-        }
+    ForceSelf<T> S;
+    S.p = posType[index];
+    if (unpack_int(S.p.w) != FSA_TYPE_FLUID) return;  // force[index] keeps its old value
+    S.v = velMass[index];
+    const T dens_i = density[index];
+    S.pterm = pressure[index] / dens_i / dens_i;
+    S.fx = S.fy = S.fz = 0;
+    force_walk_global(P, index, S, posType, velMass, density, pressure, cellStart);
     Vec3<T> f;
-    f.x = fx + (T)0;
-    f.y = fy + (T)-9.8;  // the literal of solver/sph_kernel_impl.cuh:372, not the gravity parameter
-    f.z = fz + (T)0;
+    f.x = S.fx + (T)0;
+    f.y = S.fy + (T)-9.8;  // the literal of solver/sph_kernel_impl.cuh:372, not the gravity parameter
+    f.z = S.fz + (T)0;
     force[index] = f;
 }
 
@@ -332,6 +235,7 @@ static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlo
 
 int launch_density(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    if (s->precision == FSA_PRECISION_F32 && s->variant == 1) return launch_density_tuned(s);
     ScopedTimer t(s, "density");
     const int c = s->cur;
     FSA_DISPATCH(density_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
@@ -341,6 +245,7 @@ int launch_density(Solver *s) {
 
 int launch_force(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    if (s->precision == FSA_PRECISION_F32 && s->variant == 1) return launch_force_tuned(s);
     ScopedTimer t(s, "force");
     const int c = s->cur;
     FSA_DISPATCH(force_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],

@@ -224,12 +224,19 @@ def read_raw_bounding_sphere(path):
     return c, float(np.sqrt(((v - c) ** 2).sum(1)).max())
 
 
-def jittered(scene: dict, seed=12345, pos_jitter=0.2, vel_scale=1.0) -> dict:
-    """Randomised parity input: lattice + U(-j,j)*spacing, velocities U(-v,v); PCG64 stream `seed`."""
+def jittered(scene: dict, seed=12345, pos_jitter=0.2, vel_scale=1.0, fluid_only=False) -> dict:
+    """Randomised parity input: lattice + U(-j,j)*spacing, velocities U(-v,v); PCG64 stream `seed`.
+    With fluid_only the wall particles stay where they are."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sc = dict(scene)
     sp = scene["params"]["spacing"]
     n = len(scene["pos"])
-    sc["pos"] = (scene["pos"] + rng.uniform(-pos_jitter, pos_jitter, (n, 3)).astype(F32) * F32(sp)).astype(F32)
-    sc["vel"] = rng.uniform(-vel_scale, vel_scale, (n, 3)).astype(F32)
+    dp = rng.uniform(-pos_jitter, pos_jitter, (n, 3)).astype(F32) * F32(sp)
+    dv = rng.uniform(-vel_scale, vel_scale, (n, 3)).astype(F32) if vel_scale > 0 else np.zeros((n, 3), F32)
+    if fluid_only:
+        keep = (scene["type"] != TYPE_FLUID)[:, None]
+        dp = np.where(keep, F32(0), dp)
+        dv = np.where(keep, F32(0), dv)
+    sc["pos"] = (scene["pos"] + dp).astype(F32)
+    sc["vel"] = dv.astype(F32)
     return sc

@@ -66,11 +66,17 @@ SCENES = {
 }
 
 
-@pytest.fixture(params=sorted(SCENES))
+VARIANTS = {"generic": 0, "tuned": 1}
+
+
+@pytest.fixture(params=[(sc, v) for sc in sorted(SCENES) for v in sorted(VARIANTS)],
+                ids=lambda p: f"{p[0]}-{p[1]}")
 def pair(request, orc32):
-    sc = SCENES[request.param]()
+    name, variant = request.param
+    sc = SCENES[name]()
     p_o, st = oracle_pair(orc32, sc)
     p_g, s = gpu_solver(sc)
+    s.set_variant(VARIANTS[variant])
     yield sc, p_o, st, p_g, s
     s.close()
     st.close()
@@ -162,13 +168,15 @@ def test_advect_from_same_state(pair):
         assert np.array_equal(s.get(k).view(np.int32), st[k].view(np.int32)), k
 
 
-def test_full_steps_track_oracle(orc32):
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_full_steps_track_oracle(orc32, variant):
     """20 x SolveSPH on the GPU and on the oracle from the same start.  Particles are matched by
     uniqueId; positions must agree within 1e-5 of the domain size, the particle set per cell too
     (checked through the sorted hash of the last step for all but borderline particles)."""
     sc = scenes.jittered(scenes.dam_break(14, 12, 10, tank_x_factor=2.0), seed=5, pos_jitter=0.02, vel_scale=0.02)
     p_o, st = oracle_pair(orc32, sc)
     p_g, s = gpu_solver(sc)
+    s.set_variant(VARIANTS[variant])
     steps = 20
     st.solve_sph(p_o, steps)
     s.step(steps)
@@ -186,13 +194,15 @@ def test_full_steps_track_oracle(orc32):
     s.close(); st.close()
 
 
-def test_rigid_particle_volume_and_reference_scene(orc32):
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_rigid_particle_volume_and_reference_scene(orc32, variant):
     """The shipped scene (52 272 fluid + OpenBox of TYPE_RIGID particles): RigidParticleVolume, then
     density with the rigid branch, force and advect."""
     sc = scenes.reference_scene(with_boundary=True)
     sc = scenes.jittered(sc, seed=3, pos_jitter=0.05, vel_scale=0.1)
     p_o, st = oracle_pair(orc32, sc)
     p_g, s = gpu_solver(sc)
+    s.set_variant(VARIANTS[variant])
     st.sort_particles(p_o); s.sort_particles()
     check_sorted_state(s, st)
     st.rigid_particle_volume(p_o); s.rigid_particle_volume()
