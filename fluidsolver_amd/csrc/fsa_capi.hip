@@ -703,10 +703,18 @@ int fsa_timing_read(fsa_solver *hs, fsa_kernel_time *out, int cap, int *count) {
     return FSA_OK;
 }
 
+// Not part of the public header: kernel-ablation timing used by tools/ablate.py.
+int fsa_debug_time_pass(fsa_solver *hs, int which, int ablate, int reps) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "needs a sorted state");
+    return debug_time_pass(s, which, ablate, reps);
+}
+
 int fsa_set_variant(fsa_solver *hs, int variant) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
-    if (variant < 0 || variant > 1) return fail(FSA_ERR_INVALID, "unknown variant %d", variant);
+    if (variant < 0 || variant > 2) return fail(FSA_ERR_INVALID, "unknown variant %d", variant);
     s->variant = variant;
     return FSA_OK;
 }

@@ -95,9 +95,10 @@ template <typename T> __device__ __forceinline__ bool in_domain(const DevParams<
            (double)z < (double)P.gmax[2] - FSA_EPSILON && (double)z > (double)P.gmin[2] + FSA_EPSILON;
 }
 
-// Kernel_Cubic, solver/sph_kernel_impl.cuh:32-40.
-template <typename T> __device__ __forceinline__ T kernel_cubic(const DevParams<T> &P, T h, T x, T y, T z) {
-    T q = r_sqrt(x * x + y * y + z * z) / h;
+// Kernel_Cubic, solver/sph_kernel_impl.cuh:32-40, from the squared norm d2 = x*x + y*y + z*z
+// (xij.Norm() evaluates exactly that sum before the square root).
+template <typename T> __device__ __forceinline__ T kernel_cubic_d2(const DevParams<T> &P, T h, T d2) {
+    T q = r_sqrt(d2) / h;
     T fq;
     if (q >= 2) return 0;
     if (q >= 1)
@@ -105,6 +106,9 @@ template <typename T> __device__ __forceinline__ T kernel_cubic(const DevParams<
     else
         fq = (T)((0.666667 - (double)(q * q) + 0.5 * (double)q * (double)q * (double)q) * 1.5);
     return fq * P.kernel_cubic;
+}
+template <typename T> __device__ __forceinline__ T kernel_cubic(const DevParams<T> &P, T h, T x, T y, T z) {
+    return kernel_cubic_d2(P, h, x * x + y * y + z * z);
 }
 
 }  // namespace fsa

@@ -74,7 +74,7 @@ struct Solver {
     bool index_table_valid = false;
     bool count_valid = false;   // cellStart[num_cells] holds the in-grid count of the last sort
     bool ref_cells_valid = false;
-    int variant = 1;
+    int variant = 2;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32
     // timing
     bool timing = false;
     std::vector<std::string> kernel_names;
@@ -117,6 +117,7 @@ int launch_advect(Solver *s);
 int launch_rigid_volume(Solver *s);
 int launch_density_tuned(Solver *s);
 int launch_force_tuned(Solver *s);
+int debug_time_pass(Solver *s, int which, int ablate, int reps);
 int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
 int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);
 int launch_unpack_w(Solver *s, const void *src4, void *dst, int n, bool as_int);

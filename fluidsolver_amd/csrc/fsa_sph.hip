@@ -235,7 +235,7 @@ static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlo
 
 int launch_density(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    if (s->precision == FSA_PRECISION_F32 && s->variant == 1) return launch_density_tuned(s);
+    if (s->precision == FSA_PRECISION_F32 && s->variant >= 1) return launch_density_tuned(s);
     ScopedTimer t(s, "density");
     const int c = s->cur;
     FSA_DISPATCH(density_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
@@ -245,7 +245,7 @@ int launch_density(Solver *s) {
 
 int launch_force(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    if (s->precision == FSA_PRECISION_F32 && s->variant == 1) return launch_force_tuned(s);
+    if (s->precision == FSA_PRECISION_F32 && s->variant >= 1) return launch_force_tuned(s);
     ScopedTimer t(s, "force");
     const int c = s->cur;
     FSA_DISPATCH(force_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],

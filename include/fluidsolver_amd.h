@@ -190,7 +190,12 @@ int fsa_timing_reset(fsa_solver *s);
 /* Synchronises; fills up to `cap` entries, *count = number of distinct kernels seen. */
 int fsa_timing_read(fsa_solver *s, fsa_kernel_time *out, int cap, int *count);
 
-/* variant switches for A/B measurement: 0 = generic kernels, 1 = tuned fp32 kernels (default) */
+/* Kernel variants of the density and force passes (fp32; fp64 always runs the generic kernels):
+ *   0  generic: one thread per particle reading neighbours from global memory, arithmetic
+ *      operation for operation as the reference's expressions;
+ *   1  tuned structure (LDS row tiles + per-lane hit queues), same exact arithmetic;
+ *   2  tuned structure, fast fp32 arithmetic (hardware sqrt/rsq/rcp, fused multiply-adds): about
+ *      1e-7 relative away from variant 1 per neighbour term.  Default. */
 int fsa_set_variant(fsa_solver *s, int variant);
 
 #ifdef __cplusplus

@@ -66,7 +66,7 @@ SCENES = {
 }
 
 
-VARIANTS = {"generic": 0, "tuned": 1}
+VARIANTS = {"generic": 0, "tuned": 1, "fast": 2}
 
 
 @pytest.fixture(params=[(sc, v) for sc in sorted(SCENES) for v in sorted(VARIANTS)],
@@ -77,6 +77,7 @@ def pair(request, orc32):
     p_o, st = oracle_pair(orc32, sc)
     p_g, s = gpu_solver(sc)
     s.set_variant(VARIANTS[variant])
+    s.exact_arithmetic = variant != "fast"
     yield sc, p_o, st, p_g, s
     s.close()
     st.close()
@@ -127,8 +128,9 @@ def test_density_pressure(pair):
     s.compute_pressure()
     d_g, d_o = s.get("density"), st["density"]
     assert rel_err(d_g, d_o) <= TOL
-    # same operation order and correctly rounded sqrt/div: the sums should match to the last bit
-    assert ulp_diff(d_g, d_o) <= 2
+    if s.exact_arithmetic:
+        # same operation order and correctly rounded sqrt/div: the sums should match to the last bit
+        assert ulp_diff(d_g, d_o) <= 2
     pr_g, pr_o = s.get("pressure"), st["pressure"]
     ok = np.isfinite(pr_o)
     assert np.array_equal(np.isfinite(pr_g), ok)
@@ -207,7 +209,7 @@ def test_rigid_particle_volume_and_reference_scene(orc32, variant):
     check_sorted_state(s, st)
     st.rigid_particle_volume(p_o); s.rigid_particle_volume()
     rd_g, rd_o = s.get("restDensity"), st["restDensity"]
-    assert ulp_diff(rd_g, rd_o) <= 2
+    assert ulp_diff(rd_g, rd_o) <= 2   # the set-up pass has one (exact) implementation
     s.set("restDensity", rd_o)
     st.compute_pressure(p_o); s.compute_pressure()
     fluid = st["type"] == 0
