@@ -343,6 +343,9 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
         }
     }
     FSA_HIP(hipStreamSynchronize(s->stream));
+    s->has_rigid = false;
+    for (size_t i = 0; i < N; i++)
+        if (type[i] == FSA_TYPE_RIGID) s->has_rigid = true;
     s->n = n;
     s->cur = 0;
     invalidate_order(s);
@@ -647,6 +650,11 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
         Staging st;
         TRY(st.alloc(bytes));
         if (bytes) FSA_HIP(hipMemcpy(st.d, src, bytes, hipMemcpyHostToDevice));
+        if (k == "type") {
+            s->has_rigid = false;
+            for (size_t i = 0; i < N; i++)
+                if (((const int *)src)[i] == FSA_TYPE_RIGID) s->has_rigid = true;
+        }
         TRY(launch_set_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
         FSA_HIP(hipStreamSynchronize(s->stream));
         return FSA_OK;

@@ -74,6 +74,7 @@ struct Solver {
     bool index_table_valid = false;
     bool count_valid = false;   // cellStart[num_cells] holds the in-grid count of the last sort
     bool ref_cells_valid = false;
+    bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int variant = 2;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32
     // timing
     bool timing = false;

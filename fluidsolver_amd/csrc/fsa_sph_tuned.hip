@@ -6,43 +6,44 @@
 // ("row").  The kernel walks the 9 rows in the reference's order (z outer, y inner):
 //
 //   * the row's {x, y, z, type} are copied into a small LDS buffer with coalesced 16-byte loads;
-//     two buffers alternate, the global loads of row r + 1 are issued before row r is examined
-//     and land in LDS after it, so their latency is hidden behind the arithmetic;
-//   * phase 1 (cull): every lane walks its own index range of the row, four ds_read_b128 in
-//     flight, and appends the candidates that pass the distance test to its private queue in LDS
-//     (queue[slot][lane]: conflict-free; 16-bit entries = row number and index inside the row);
+//     two buffers alternate, the global loads of row r + 1 (and of the lane's cell range in it)
+//     are issued before row r is examined and land after it, so their latency is hidden;
+//   * phase 1 (cull): every lane walks its own index range of the row four candidates at a time
+//     (four ds_read_b128 in flight, straight-line code, no divergent branches) and appends those
+//     that pass the distance test to its private queue in LDS (queue[slot][lane]: conflict-free).
+//     The append is branch-free: all four candidates are stored, each at the slot counted up by
+//     the hits before it, so a miss is simply overwritten by the next store;
 //   * phase 2 (evaluate): when a queue nears its capacity, and after the last row, the wavefront
-//     drains the queues: every lane evaluates its queued neighbours, so the expensive arithmetic
-//     runs with most lanes busy.  Queues are first-in first-out, so each particle's sum is
-//     accumulated in the reference's neighbour order.
+//     drains the queues four entries per trip, so the expensive arithmetic runs with most lanes
+//     busy.  Queues are first-in first-out: each particle's sum is accumulated in the reference's
+//     neighbour order.
 //
-// LDS per workgroup is about 32 KiB, which keeps five workgroups (20 wavefronts) on a CU: the
-// VALU of gfx950 needs at least four wavefronts per SIMD to issue at its full rate.
+// LDS per workgroup is 29-37 KiB, which keeps four workgroups (16 wavefronts) on a CU: the VALU
+// of gfx950 needs about four wavefronts per SIMD to issue at its full rate.
 //
 // Two arithmetic flavours share this structure:
-//   EXACT: the pair routines of fsa_pair.h (operation for operation the reference's expressions).
+//   EXACT: the expressions of fsa_pair.h / fsa_device.h, operation for operation the reference's.
 //   FAST : fp32 only, v_sqrt/v_rsq/v_rcp and fused multiply-adds; differs from EXACT by a few
 //          units in the last place per pair (about 1e-7 relative in density and force).
 //
-// Workgroups whose rows do not fit the buffers (very sparse or very crowded regions) or that hold
-// out-of-grid particles take the generic global-memory walk with the exact routines.
+// Workgroups whose rows do not fit the buffers (very crowded regions) or that hold out-of-grid
+// particles take the generic global-memory walk with the exact routines.
 #include <cstdlib>
+#include <type_traits>
 
 #include "fsa_pair.h"
 #include "fsa_solver.h"
 
 namespace fsa {
 
-constexpr int kChunk = 4;     // candidates fetched per lane and loop trip
-constexpr int kCellCap = 96;  // cell-start entries staged per row
+constexpr int kChunk = 4;  // candidates fetched per lane and loop trip
+constexpr int kDrainBatch = 2;  // force drain: neighbours per batch (two batches in flight)
 constexpr float kFar = 3.0e18f;
 
 template <int BS, int ROWCAP> struct RowShared {
     float4 row[2][ROWCAP + kChunk];  // + far-away padding read by the last chunk of a lane
-    int cellL[9 * kCellCap];         // cell starts of the 9 rows, relative to the row's first particle
     int rowStartG[9];                // first particle (global index) of each row
     int rowLen[9];
-    int rowCell0[9];                 // first cell of each row
     int staged;
 };
 
@@ -50,30 +51,24 @@ template <int BS, int ROWCAP> struct RowShared {
 template <int BS, int ROWCAP>
 __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, int nb,
                                            const int *__restrict__ cellStart,
-                                           const int *__restrict__ sortedHash, RowShared<BS, ROWCAP> &sh,
-                                           int ablate = 0) {
+                                           const int *__restrict__ sortedHash, RowShared<BS, ROWCAP> &sh) {
     const int tid = threadIdx.x;
     const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
     const int C = P.num_cells;
-    // gx >= 4: a candidate that lies in the same hash row but outside a lane's three cells is then at
-    // least one cell (= one smoothing radius) away in x, so it can never pass the distance test
-    const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF && (long long)hhi - (long long)hlo + 4 <= kCellCap &&
-                         P.gres[0] >= 4;
+    const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
     if (tid < 9) {
-        int s = 0, len = -1, c0 = 0;
+        int s = 0, len = -1;
         if (grid_ok) {
             const int dz = tid / 3 - 1, dy = tid % 3 - 1;
             const long long off = (long long)dy * P.gres[0] * P.nz + (long long)dz * P.gres[0];
             long long a = (long long)hlo + off - 1, b = (long long)hhi + off + 2;
             a = a < 0 ? 0 : (a > C ? C : a);
             b = b < 0 ? 0 : (b > C ? C : b);
-            c0 = (int)a;
             s = cellStart[a];
             len = cellStart[b] - s;
         }
         sh.rowStartG[tid] = s;
         sh.rowLen[tid] = len;
-        sh.rowCell0[tid] = c0;
     }
     __syncthreads();
     if (tid == 0) {
@@ -83,21 +78,14 @@ __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, in
         sh.staged = ok ? 1 : 0;
     }
     __syncthreads();
-    if (!sh.staged) return false;
-    const int ncell = (int)(hhi - hlo) + 4;  // entries per row: cells hlo-1 .. hhi+2
-    for (int t = tid; t < 9 * ncell && !(ablate & 16); t += BS) {
-        const int r = t / ncell, k = t - r * ncell;
-        long long c = (long long)sh.rowCell0[r] + k;
-        if (c > C) c = C;
-        sh.cellL[r * kCellCap + k] = cellStart[c] - sh.rowStartG[r];
-    }
-    return true;
+    return sh.staged != 0;
 }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // Row r of the tile: every thread fetches its (at most two) entries into registers ...
-template <int BS, int ROWCAP>
+// FLUID_ONLY: particles of any other type are moved far away, so that the cull needs no type test.
+template <int BS, int ROWCAP, bool FLUID_ONLY>
 __device__ __forceinline__ void row_fetch(const RowShared<BS, ROWCAP> &sh, int r,
                                           const float4 *__restrict__ posType, float4 &e0, float4 &e1) {
     static_assert(ROWCAP + kChunk <= 2 * BS, "two entries per thread must cover a row");
@@ -107,8 +95,9 @@ __device__ __forceinline__ void row_fetch(const RowShared<BS, ROWCAP> &sh, int r
     const int last = len > 0 ? len - 1 : 0;
     e0 = posType[s + min(tid, last)];
     e1 = posType[s + min(tid + BS, last)];
-    if (tid >= len) e0 = make_float4(kFar, kFar, kFar, __int_as_float(-1));
-    if (tid + BS >= len) e1 = make_float4(kFar, kFar, kFar, __int_as_float(-1));
+    const float4 far = make_float4(kFar, kFar, kFar, 0.0f);
+    if (tid >= len || (FLUID_ONLY && unpack_int(e0.w) != FSA_TYPE_FLUID)) e0 = far;
+    if (tid + BS >= len || (FLUID_ONLY && unpack_int(e1.w) != FSA_TYPE_FLUID)) e1 = far;
 }
 // ... and stores them later, after the previous row has been examined.
 template <int BS, int ROWCAP>
@@ -118,23 +107,42 @@ __device__ __forceinline__ void row_store(RowShared<BS, ROWCAP> &sh, int buf, co
     if (tid + BS < ROWCAP + kChunk) sh.row[buf][tid + BS] = e1;
 }
 
-// ---- fast fp32 pair arithmetic -----------------------------------------------------------------
-struct FastConst {
-    float sr, sr2, inv_h, kcubic, kspiky, visc_eps;  // visc_eps = 0.01 * sr^2
-};
+// The lane's index range in row r, relative to the row's first particle (two loads of the cell table).
+template <int BS, int ROWCAP>
+__device__ __forceinline__ void lane_range(const DevParams<float> &P, const RowShared<BS, ROWCAP> &sh,
+                                           const RowWalk<float> &walk, bool active, int r,
+                                           const int *__restrict__ cellStart, int &lj, int &le) {
+    lj = 0;
+    le = 0;
+    if (active) {
+        const int c = walk.row_cell(P, r % 3 - 1, r / 3 - 1);
+        if (c >= 0) {
+            const int s = sh.rowStartG[r];
+            lj = cellStart[c] - s;
+            le = cellStart[c + (walk.xhi - walk.xlo) + 1] - s;
+        }
+    }
+}
 
-__device__ __forceinline__ float cubic_fast(const FastConst &K, float d2) {
-    const float q = __builtin_amdgcn_sqrtf(d2) * K.inv_h;
+// ---- fast fp32 pair arithmetic -----------------------------------------------------------------
+__device__ __forceinline__ float cubic_fast(float d2, float inv_h, float kcubic) {
+    const float q = __builtin_amdgcn_sqrtf(d2) * inv_h;
     // q < 1: (0.666667 - q^2 + 0.5 q^3) * 1.5     1 <= q < 2: 0.25 (2 - q)^3
     const float q2 = q * q;
     const float w1 = __builtin_fmaf(q2, __builtin_fmaf(0.75f, q, -1.5f), 1.0000005f);
     const float t = 2.0f - q;
     const float w2 = 0.25f * t * t * t;
-    return (q < 1.0f ? w1 : w2) * K.kcubic;
+    return (q < 1.0f ? w1 : w2) * kcubic;
 }
 
+static int g_ablate = 0;        // timing experiments only (debug_time_pass)
+static void *g_out0 = nullptr;  // when set, results go to these scratch arrays instead
+static void *g_out1 = nullptr;
+
 // ------------------------------------------------------------------------------------------------
-// density + pressure
+// density + pressure.  Scenes with TYPE_RIGID particles use the generic kernel (the rigid term
+// needs the neighbour's restDensity); here only fluid neighbours count, so the queue holds nothing
+// but their squared distances.
 // ------------------------------------------------------------------------------------------------
 template <int BS, int ROWCAP, int Q, bool FAST>
 __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, int n,
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     const bool active = index < n;
-    const bool staged = setup_rows<BS, ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, ablate);
+    const bool staged = setup_rows<BS, ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -168,81 +176,91 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     } else {
         const float sr = P.sr, sr2 = sr * sr;
         const float h = (float)((double)sr * 0.5);
-        FastConst K;
-        K.sr = sr; K.sr2 = sr2; K.inv_h = 1.0f / h; K.kcubic = P.kernel_cubic; K.kspiky = P.kspikydiff;
-        K.visc_eps = 0.01f * sr2;
+        const float inv_h = 1.0f / h, kcubic = P.kernel_cubic;
         const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
-        int cnt = 0;
-        // Queue entries are the squared distances of the fluid neighbours found: the density
-        // contribution depends on nothing else.  A TYPE_RIGID neighbour also needs its own
-        // restDensity, so it takes two slots: -(global index + 1) as an integer, then d2.
         float *const q = queue + tid;
+        int cnt = 0;
         auto drain = [&]() {
             if (ablate & 1) { cnt = 0; return; }
-            for (int s = 0; wave_any(s < cnt); s++) {
-                if (s < cnt) {
-                    float d2 = q[s * BS];
-                    float coef = mass_i;
-                    if (__float_as_int(d2) < 0) {  // rigid marker (a squared distance is never negative)
-                        coef = rd_i * restDensity[-__float_as_int(d2) - 1];
-                        s++;
-                        d2 = q[s * BS];
+            for (int s = 0; wave_any(s < cnt); s += kChunk) {
+                float d2[kChunk];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) d2[u] = q[(s + u) * BS];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    if (FAST) {
+                        const float w = s + u < cnt ? cubic_fast(d2[u], inv_h, kcubic) : 0.0f;
+                        dens = __builtin_fmaf(mass_i, w, dens);
+                    } else if (s + u < cnt) {
+                        dens += mass_i * kernel_cubic_d2(P, h, d2[u]);
                     }
-                    if (FAST)
-                        dens = __builtin_fmaf(coef, cubic_fast(K, d2), dens);
-                    else
-                        dens += coef * kernel_cubic_d2(P, h, d2);
                 }
             }
             cnt = 0;
         };
 
         float4 e0, e1;
-        row_fetch(sh, 0, posType, e0, e1);
+        int lj, le, nlj = 0, nle = 0;
+        row_fetch<BS, ROWCAP, true>(sh, 0, posType, e0, e1);
+        lane_range(P, sh, walk, active, 0, cellStart, lj, le);
         row_store(sh, 0, e0, e1);
-        __syncthreads();  // row 0 and cellL are in LDS
+        __syncthreads();
         for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
             const int buf = r & 1;
-            if (r + 1 < 9) row_fetch(sh, r + 1, posType, e0, e1);  // in flight during the cull below
-            int lj = 0, le = 0;
-            if (active) {
-                const int c = walk.row_cell(P, r % 3 - 1, r / 3 - 1);
-                if (c >= 0) {
-                    const int rel = r * kCellCap + (c - sh.rowCell0[r]);
-                    lj = sh.cellL[rel];
-                    le = sh.cellL[rel + (walk.xhi - walk.xlo) + 1];
-                }
+            if (r + 1 < 9) {  // in flight during the cull below
+                row_fetch<BS, ROWCAP, true>(sh, r + 1, posType, e0, e1);
+                lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
             }
             const float4 *__restrict__ row = sh.row[buf];
-            const int gofs = sh.rowStartG[r];
             if (ablate & 4) lj = le;
-            while (wave_any(lj < le)) {
-                const int base = lj < le ? lj : ROWCAP;  // finished lanes read the far-away padding
+            // full chunks: all four candidates belong to the lane's range
+            while (wave_any(lj + kChunk <= le)) {
+                const bool go = lj + kChunk <= le;
+                const int base = go ? lj : ROWCAP;  // lanes with less than a chunk left read far-away padding
                 float4 c4[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) c4[u] = row[base + u];
+                float d2[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
                     const float xx = pi.x - c4[u].x, xy = pi.y - c4[u].y, xz = pi.z - c4[u].z;
-                    const float d2 = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx))
-                                          : xx * xx + xy * xy + xz * xz;
-                    const int tj = unpack_int(c4[u].w);
-                    if (d2 < sr2 && !(ablate & 2)) {
-                        if (tj == FSA_TYPE_FLUID) {
-                            q[cnt * BS] = d2;
-                            cnt++;
-                        } else if (tj == FSA_TYPE_RIGID) {
-                            q[cnt * BS] = __int_as_float(-(gofs + base + u) - 1);
-                            q[(cnt + 1) * BS] = d2;
-                            cnt += 2;
-                        }
+                    d2[u] = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx))
+                                 : xx * xx + xy * xy + xz * xz;
+                }
+                if (!(ablate & 2)) {
+#pragma unroll
+                    for (int u = 0; u < kChunk; u++) {
+                        q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
+                        cnt += d2[u] < sr2 ? 1 : 0;
                     }
                 }
-                lj += kChunk;
-                if (wave_any(cnt > Q - 2 * kChunk)) drain();
+                lj += go ? kChunk : 0;
+                if (wave_any(cnt > Q - kChunk)) drain();
+            }
+            // tail: the last one to three candidates of the range (what follows them in the row belongs
+            // to other cells and may well be close, so it is masked out)
+            if (wave_any(lj < le)) {
+                const int rem = le - lj;  // 0..3
+                const int base = rem > 0 ? lj : ROWCAP;
+                float4 c4[kChunk - 1];
+#pragma unroll
+                for (int u = 0; u < kChunk - 1; u++) c4[u] = row[base + u];
+#pragma unroll
+                for (int u = 0; u < kChunk - 1; u++) {
+                    const float xx = pi.x - c4[u].x, xy = pi.y - c4[u].y, xz = pi.z - c4[u].z;
+                    const float d2 = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx))
+                                          : xx * xx + xy * xy + xz * xz;
+                    if (!(ablate & 2)) {
+                        q[cnt * BS] = d2;
+                        cnt += (d2 < sr2 && u < rem) ? 1 : 0;
+                    }
+                }
+                if (wave_any(cnt > Q - kChunk)) drain();
             }
             if (r + 1 < 9) {
                 row_store(sh, buf ^ 1, e0, e1);
+                lj = nlj;
+                le = nle;
                 __syncthreads();  // row r + 1 visible; everyone is done with row r - 1's buffer
             }
         }
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                                                          const int *__restrict__ sortedHash,
                                                          Vec3<float> *__restrict__ force, int ablate) {
     __shared__ RowShared<BS, ROWCAP> sh;
-    __shared__ unsigned short queue[Q * BS];
+    __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * BS;
     const int nb = min(BS, n - b0);
@@ -311,109 +329,159 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     const float sr = P.sr, sr2 = sr * sr;
     if (!staged) {
-        if (active) force_walk_global(P, index, S, posType, velMass, density, pressure, cellStart);
+        if (active && !(ablate & 32))
+            force_walk_global(P, index, S, posType, velMass, density, pressure, cellStart);
     } else {
-        FastConst K;
-        K.sr = sr; K.sr2 = sr2; K.inv_h = 0.f; K.kcubic = 0.f; K.kspiky = P.kspikydiff;
-        K.visc_eps = 0.01f * sr2;
-        const float sr2c = FAST ? sr2 : sr2 * 1.000002f;
+        const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+        const float sr2c = FAST ? sr2 : sr2 * 1.000002f;  // the unfused test of EXACT comes later
         const RowWalk<float> walk(P, S.p.x, S.p.y, S.p.z);
+        unsigned short *const q = queue + tid;
+        const int safe = index < n ? index : 0;
         int cnt = 0;
 
-        auto evaluate = [&](int j, const float4 &pj, const float4 &vj, const float2 &aj) {
-            const int tj = unpack_int(pj.w);
-            if (FAST && tj == FSA_TYPE_FLUID) {
-                const float xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
-                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                if (d2 < sr2 && j != index) {
+        // exact routine: TYPE_BOUNDARY neighbours always, fluid neighbours in the EXACT flavour
+        auto evaluate_exact = [&](int j, const float4 &pj, const float4 &vj, const float2 &aj) {
+            const float xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
+            const float d2 = xx * xx + xy * xy + xz * xz;
+            if (force_pair_active(unpack_int(pj.w), j == index, d2, sr2))
+                force_pair(P, sr, sr2, S, j == index, pj, vj, aj.x, FAST ? 1.0f : aj.y);
+        };
+        // One batch of the drain: DB neighbours whose loads are issued together.
+        struct Batch {
+            int j[kDrainBatch];
+            float4 pj[kDrainBatch], vj[kDrainBatch];
+            float2 aj[kDrainBatch];
+        };
+        auto batch_load = [&](Batch &B, int s) {
+#pragma unroll
+            for (int u = 0; u < kDrainBatch; u++) {
+                const int e = q[(s + u) * BS];
+                B.j[u] = (s + u < cnt && !(ablate & 64)) ? sh.rowStartG[e >> 9] + (e & 511) : safe;
+            }
+#pragma unroll
+            for (int u = 0; u < kDrainBatch; u++) {
+                B.pj[u] = posType[B.j[u]];
+                B.vj[u] = velMass[B.j[u]];
+                B.aj[u] = pd[B.j[u]];
+            }
+        };
+        auto batch_eval = [&](const Batch &B, int s) {
+            if (FAST) {
+                bool other = false;
+#pragma unroll
+                for (int u = 0; u < kDrainBatch; u++) {
+                    // straight-line: an entry that does not count (slot past the end, self, out of
+                    // range, not a fluid particle) is evaluated anyway and then zeroed by selects
+                    const float xx = S.p.x - B.pj[u].x, xy = S.p.y - B.pj[u].y, xz = S.p.z - B.pj[u].z;
+                    const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                    const int tj = unpack_int(B.pj[u].w);
+                    const bool ok = d2 < sr2 && B.j[u] != index && tj == FSA_TYPE_FLUID;
+                    other |= tj != FSA_TYPE_FLUID && s + u < cnt;
                     const float rinv = __builtin_amdgcn_rsqf(d2);
                     const float c = sr - d2 * rinv;
-                    const float nablaw = K.kspiky * c * c * rinv;
-                    const float pc = nablaw * vj.w * (aj.x + S.pterm);
+                    const float nablaw = kspiky * c * c * rinv;
+                    const float pc = ok ? nablaw * B.vj[u].w * (B.aj[u].x + S.pterm) : 0.0f;
+                    const float vc = ok ? nablaw * d2 * __builtin_amdgcn_rcpf(d2 + visc_eps) * B.aj[u].y : 0.0f;
                     S.fx = __builtin_fmaf(-xx, pc, S.fx);
                     S.fy = __builtin_fmaf(-xy, pc, S.fy);
                     S.fz = __builtin_fmaf(-xz, pc, S.fz);
-                    const float vc = nablaw * d2 * __builtin_amdgcn_rcpf(d2 + K.visc_eps) * aj.y;
-                    S.fx = __builtin_fmaf(S.v.x - vj.x, vc, S.fx);
-                    S.fy = __builtin_fmaf(S.v.y - vj.y, vc, S.fy);
-                    S.fz = __builtin_fmaf(S.v.z - vj.z, vc, S.fz);
+                    S.fx = __builtin_fmaf(S.v.x - B.vj[u].x, vc, S.fx);
+                    S.fy = __builtin_fmaf(S.v.y - B.vj[u].y, vc, S.fy);
+                    S.fz = __builtin_fmaf(S.v.z - B.vj[u].z, vc, S.fz);
+                }
+                if (wave_any(other)) {  // wall particles among them (rare)
+#pragma unroll
+                    for (int u = 0; u < kDrainBatch; u++)
+                        if (s + u < cnt && unpack_int(B.pj[u].w) != FSA_TYPE_FLUID)
+                            evaluate_exact(B.j[u], B.pj[u], B.vj[u], B.aj[u]);
                 }
             } else {
-                const float xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
-                const float d2 = xx * xx + xy * xy + xz * xz;
-                if (force_pair_active(tj, j == index, d2, sr2)) {
-                    // the boundary branch needs no per-particle term; the fluid branch only runs here for EXACT
-                    force_pair(P, sr, sr2, S, j == index, pj, vj, aj.x, FAST ? 1.0f : aj.y);
-                }
+#pragma unroll
+                for (int u = 0; u < kDrainBatch; u++)
+                    if (s + u < cnt) evaluate_exact(B.j[u], B.pj[u], B.vj[u], B.aj[u]);
             }
         };
-        const int safe = index < n ? index : 0;
         auto drain = [&]() {
             if (ablate & 1) { cnt = 0; return; }
-            // four neighbours per trip: their 12 loads are in flight together before any is evaluated
-            for (int s = 0; wave_any(s < cnt); s += kChunk) {
-                int j[kChunk];
-                float4 pj[kChunk], vj[kChunk];
-                float2 aj[kChunk];
-#pragma unroll
-                for (int u = 0; u < kChunk; u++) {
-                    const int e = queue[(s + u) * BS + tid];
-                    j[u] = s + u < cnt ? sh.rowStartG[e >> 9] + (e & 511) : safe;
-                }
-#pragma unroll
-                for (int u = 0; u < kChunk; u++) {
-                    pj[u] = posType[j[u]];
-                    vj[u] = velMass[j[u]];
-                    aj[u] = pd[j[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < kChunk; u++)
-                    if (s + u < cnt) evaluate(j[u], pj[u], vj[u], aj[u]);
+            // double-buffered: the loads of batch k + 1 are in flight while batch k is evaluated
+            Batch B0, B1;
+            batch_load(B0, 0);
+            for (int s = 0; wave_any(s < cnt); s += 2 * kDrainBatch) {
+                batch_load(B1, s + kDrainBatch);
+                batch_eval(B0, s);
+                if (!wave_any(s + kDrainBatch < cnt)) break;
+                batch_load(B0, s + 2 * kDrainBatch);
+                batch_eval(B1, s + kDrainBatch);
             }
             cnt = 0;
         };
 
         float4 e0, e1;
-        row_fetch(sh, 0, posType, e0, e1);
+        int lj, le, nlj = 0, nle = 0;
+        row_fetch<BS, ROWCAP, false>(sh, 0, posType, e0, e1);
+        lane_range(P, sh, walk, active, 0, cellStart, lj, le);
         row_store(sh, 0, e0, e1);
         __syncthreads();
-        for (int r = 0; r < 9; r++) {
+        for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
             const int buf = r & 1;
-            if (r + 1 < 9) row_fetch(sh, r + 1, posType, e0, e1);
-            int lj = 0, le = 0;
-            if (active) {
-                const int c = walk.row_cell(P, r % 3 - 1, r / 3 - 1);
-                if (c >= 0) {
-                    const int rel = r * kCellCap + (c - sh.rowCell0[r]);
-                    lj = sh.cellL[rel];
-                    le = sh.cellL[rel + (walk.xhi - walk.xlo) + 1];
-                }
+            if (r + 1 < 9) {
+                row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e0, e1);
+                lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
             }
             const float4 *__restrict__ row = sh.row[buf];
             const int tag = r << 9;
             if (ablate & 4) lj = le;
-            while (wave_any(lj < le)) {
-                const int base = lj < le ? lj : ROWCAP;
-                float4 c4[kChunk];
+            // One chunk of NU candidates starting at `base`; `rem` = how many of them belong to the lane.
+            auto cull_chunk = [&](int base, int rem, auto nu_tag) {
+                constexpr int NU = decltype(nu_tag)::value;
+                float4 c4[NU];
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) c4[u] = row[base + u];
+                for (int u = 0; u < NU; u++) c4[u] = row[base + u];
+                float d2[NU];
+                int types = 0;
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) {
+                for (int u = 0; u < NU; u++) {
                     const float xx = S.p.x - c4[u].x, xy = S.p.y - c4[u].y, xz = S.p.z - c4[u].z;
-                    const float d2c = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                    const int tj = unpack_int(c4[u].w);
-                    // fluid neighbours inside the support; boundary neighbours of the lane's own cells always
-                    if (((d2c < sr2c && tj == FSA_TYPE_FLUID) || (tj == FSA_TYPE_BOUNDARY && base + u < le)) &&
-                        !(ablate & 2)) {
-                        queue[cnt * BS + tid] = (unsigned short)(tag | (base + u));
-                        cnt++;
+                    d2[u] = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                    types |= unpack_int(c4[u].w);
+                }
+                const int etag = tag | base;
+                if (ablate & 2) {
+                } else if (!wave_any(types != 0)) {
+                    // only fluid candidates (the common case): branch-free append
+#pragma unroll
+                    for (int u = 0; u < NU; u++) {
+                        q[cnt * BS] = (unsigned short)(etag + u);  // a miss is overwritten by the next store
+                        cnt += (d2[u] < sr2c && u < rem) ? 1 : 0;
+                    }
+                } else {
+                    // wall or other particles among the candidates: boundary neighbours always count,
+                    // fluid ones inside the support, everything else never
+#pragma unroll
+                    for (int u = 0; u < NU; u++) {
+                        const int tj = unpack_int(c4[u].w);
+                        if (u < rem && ((tj == FSA_TYPE_FLUID && d2[u] < sr2c) || tj == FSA_TYPE_BOUNDARY)) {
+                            q[cnt * BS] = (unsigned short)(etag + u);
+                            cnt++;
+                        }
                     }
                 }
-                lj += kChunk;
+            };
+            while (wave_any(lj + kChunk <= le)) {  // full chunks
+                const bool go = lj + kChunk <= le;
+                cull_chunk(go ? lj : ROWCAP, go ? kChunk : 0, std::integral_constant<int, kChunk>());
+                lj += go ? kChunk : 0;
+                if (wave_any(cnt > Q - kChunk)) drain();
+            }
+            if (wave_any(lj < le)) {  // tail: the last one to three candidates of the range
+                const int rem = le - lj;
+                cull_chunk(rem > 0 ? lj : ROWCAP, rem, std::integral_constant<int, kChunk - 1>());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
             if (r + 1 < 9) {
                 row_store(sh, buf ^ 1, e0, e1);
+                lj = nlj;
+                le = nle;
                 __syncthreads();
             }
         }
@@ -433,12 +501,8 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
 // ------------------------------------------------------------------------------------------------
 constexpr int kTunedBS = 256;
 constexpr int kRowCap = 384;  // typical row: 34 cells x 8 particles = 272
-constexpr int kQueueD = 24;  // density: 4-byte slots
-constexpr int kQueueF = 32;  // force: 2-byte slots
-
-static int g_ablate = 0;         // timing experiments only (fsa_debug_time_pass)
-static void *g_out0 = nullptr;   // when set, results go to these scratch arrays instead
-static void *g_out1 = nullptr;
+constexpr int kQueueD = 24;   // density: 4-byte slots
+constexpr int kQueueF = 32;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
@@ -446,18 +510,15 @@ int launch_density_tuned(Solver *s) {
     ScopedTimer t(s, g_out0 ? "density_dbg" : "density");
     const int c = s->cur;
     const int nb = (s->n + kTunedBS - 1) / kTunedBS;
+    float *out0 = (float *)(g_out0 ? g_out0 : s->b.density), *out1 = (float *)(g_out1 ? g_out1 : s->b.pressure);
     if (s->variant == 2)
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, true>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
-                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash,
-                           (float *)(g_out0 ? g_out0 : s->b.density), (float *)(g_out1 ? g_out1 : s->b.pressure),
-                           ablate);
+                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, ablate);
     else
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, false>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
-                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash,
-                           (float *)(g_out0 ? g_out0 : s->b.density), (float *)(g_out1 ? g_out1 : s->b.pressure),
-                           ablate);
+                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, ablate);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
@@ -481,16 +542,17 @@ int launch_force_tuned(Solver *s) {
     ScopedTimer t(s, g_out0 ? "force_dbg" : "force");
     const int nb = (s->n + kTunedBS - 1) / kTunedBS;
     const int ablate = g_ablate;
+    Vec3<float> *out = (Vec3<float> *)(g_out0 ? g_out0 : s->b.force);
     if (fast)
         hipLaunchKernelGGL((force_tuned_kernel<kTunedBS, kRowCap, kQueueF, true>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                            (const float *)s->b.density, (const float *)s->b.pressure, (const float2 *)s->b.pd,
-                           s->b.cellStart, s->b.sortedHash, (Vec3<float> *)(g_out0 ? g_out0 : s->b.force), ablate);
+                           s->b.cellStart, s->b.sortedHash, out, ablate);
     else
         hipLaunchKernelGGL((force_tuned_kernel<kTunedBS, kRowCap, kQueueF, false>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                            (const float *)s->b.density, (const float *)s->b.pressure, (const float2 *)s->b.pd,
-                           s->b.cellStart, s->b.sortedHash, (Vec3<float> *)(g_out0 ? g_out0 : s->b.force), ablate);
+                           s->b.cellStart, s->b.sortedHash, out, ablate);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
