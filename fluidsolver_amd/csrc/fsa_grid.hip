@@ -42,11 +42,26 @@ __global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, cons
         hash[i] = (int)h;
     }
     const bool undef = valid && h == FSA_GRID_UNDEF;
-    int my = 0;
-    if (valid && !undef) my = atomicAdd(&cellCount[h], 1);
-
-    const unsigned long long m = __ballot(undef);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // One atomic per run of equal cells inside the wavefront instead of one per particle: after the
+    // first step the input is almost sorted, so a run is usually a whole cell.  The run leader adds the
+    // run length and hands the base to the others; the order inside a cell is settled later (rank).
+    int my = 0;
+    {
+        const bool counts = valid && !undef;
+        const unsigned hprev = (unsigned)__shfl_up((int)h, 1, 64);
+        const bool start = lane == 0 || !counts || h != hprev;
+        const unsigned long long starts = __ballot(start);
+        const unsigned long long upto = starts & ((2ull << lane) - 1ull);     // run starts at or below this lane
+        const unsigned long long above = starts & ~((2ull << lane) - 1ull);  // run starts above it
+        const int leader = 63 - __clzll((long long)upto);
+        const int next = above ? __ffsll((long long)above) - 1 : 64;
+        int base = 0;
+        if (counts && lane == leader) base = atomicAdd(&cellCount[h], next - leader);
+        base = __shfl(base, leader, 64);
+        if (counts) my = base + (lane - leader);
+    }
+    const unsigned long long m = __ballot(undef);
     if (lane == 0) waveCount[wave] = __popcll(m);
     __syncthreads();
     if (undef) {
