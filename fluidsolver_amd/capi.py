@@ -5,7 +5,9 @@ There is no fallback: if the HIP library is missing or a call fails, an exceptio
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -27,6 +29,7 @@ EXPORTS = (
     "fsa_sort_particles", "fsa_compute_pressure", "fsa_compute_force", "fsa_advect",
     "fsa_rigid_particle_volume", "fsa_step", "fsa_readback_pos_color", "fsa_get_buffer", "fsa_set_buffer",
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant",
+    "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_set_scene_has_rigid",
 )
 
 
@@ -58,6 +61,26 @@ class KernelTime(C.Structure):
 _lib = None
 
 
+def _bind_to_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels ship their own libamdhip64 / libhsa-runtime64.  Two copies of the runtime in
+    one process cannot both open the GPU, so when torch is installed but not imported yet, its copy is
+    loaded first and this library's libamdhip64.so.7 dependency resolves to it (same SONAME), whichever
+    of the two gets imported first.  FSA_SYSTEM_HIP=1 keeps the system runtime."""
+    if "torch" in sys.modules or os.environ.get("FSA_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load the shared library once and declare the prototypes."""
     global _lib
@@ -66,6 +89,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise FsaError(f"{LIB_PATH} is missing: build it with `make -C fluidsolver_amd/csrc` "
                        "(or __graft_entry__.build()); there is no CPU fallback")
+    _bind_to_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     H, P = C.c_void_p, C.POINTER(Params)
     lib.fsa_last_error.restype = C.c_char_p
@@ -92,6 +116,11 @@ def load() -> C.CDLL:
         "fsa_timing_enable": [H, C.c_int], "fsa_timing_reset": [H],
         "fsa_timing_read": [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)],
         "fsa_set_variant": [H, C.c_int],
+        "fsa_slab_record_bytes": [H, C.POINTER(C.c_int)],
+        "fsa_slab_pack": [H] + [C.POINTER(C.c_int)] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                           C.POINTER(C.c_int)],
+        "fsa_slab_unpack": [H, C.c_void_p, C.c_int],
+        "fsa_set_scene_has_rigid": [H, C.c_int],
     }
     for name, args in protos.items():
         f = getattr(lib, name)
@@ -137,6 +166,7 @@ BUFFERS = {
     "type": ("i", 1), "group": ("i", 1), "uniqueId": ("i", 1), "indexTable": ("i", 1),
     "particleHash": ("i", 1), "particleIndex": ("i", 1),
     "gridCellStart": ("c", 0), "gridCellEnd": ("c", 0), "cellStartDense": ("c", 1),
+    "orderKey": ("l", 1),
 }
 
 
@@ -213,6 +243,8 @@ class Solver:
             out = np.empty((n, w) if w > 1 else (n,), dtype=self.dtype)
         elif kind == "i":
             out = np.empty((n,), dtype=np.int32)
+        elif kind == "l":
+            out = np.empty((n,), dtype=np.int64)
         else:
             out = np.empty((self.num_cells + w,), dtype=np.int32)
         check(self.lib.fsa_get_buffer(self._h, name.encode(), _ptr(out), out.nbytes))
@@ -250,6 +282,28 @@ class Solver:
     def synchronize(self): check(self.lib.fsa_synchronize(self._h))
     def set_stream(self, stream_ptr): check(self.lib.fsa_set_stream(self._h, C.c_void_p(stream_ptr)))
     def set_variant(self, v: int): check(self.lib.fsa_set_variant(self._h, int(v)))
+
+    # -- z-slab decomposition --------------------------------------------------------
+    @property
+    def slab_record_bytes(self) -> int:
+        b = C.c_int()
+        check(self.lib.fsa_slab_record_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def slab_pack(self, own, keep, left, right, send_left_ptr, cap_left, send_right_ptr, cap_right):
+        """-> (remaining, records_left, records_right, lost); the pointers are device addresses."""
+        i2 = C.c_int * 2
+        counts = (C.c_int * 4)()
+        check(self.lib.fsa_slab_pack(self._h, i2(*own), i2(*keep), i2(*left), i2(*right),
+                                     C.c_void_p(send_left_ptr), int(cap_left), C.c_void_p(send_right_ptr),
+                                     int(cap_right), counts))
+        return tuple(counts)
+
+    def slab_unpack(self, records_ptr, count):
+        check(self.lib.fsa_slab_unpack(self._h, C.c_void_p(records_ptr), int(count)))
+
+    def set_scene_has_rigid(self, flag: bool):
+        check(self.lib.fsa_set_scene_has_rigid(self._h, 1 if flag else 0))
 
     # -- measurement ------------------------------------------------------------------
     def timing_enable(self, on=True): check(self.lib.fsa_timing_enable(self._h, 1 if on else 0))

@@ -105,7 +105,7 @@ static void free_all(Solver *s) {
                     b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.pd, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
-                    b.indexTable};
+                    b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &t : s->launches) {
@@ -233,6 +233,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     to_dev_params(*p, s->pf);
     to_dev_params(*p, s->pd);
     s->num_cells = s->pf.num_cells;
+    s->slab = p->slab_nz > 0;
 
     int rc = activate(s);
     if (rc == FSA_OK && hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess)
@@ -270,10 +271,16 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
     ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);
     ALLOC(b.undefBlockStart, (nblocks + 8) * sizeof(int), true);
-    ALLOC(b.color, N * 4 * R, true);
-    ALLOC(b.normal, N * 3 * R, true);
-    ALLOC(b.group, N * sizeof(int), true);
-    ALLOC(b.indexTable, N * sizeof(int), true);
+    if (!s->slab) {  // indexed by uniqueId, which is a global id in a slab run
+        ALLOC(b.color, N * 4 * R, true);
+        ALLOC(b.normal, N * 3 * R, true);
+        ALLOC(b.group, N * sizeof(int), true);
+        ALLOC(b.indexTable, N * sizeof(int), true);
+    } else {
+        ALLOC(b.orderKey[0], N * sizeof(long long), true);
+        ALLOC(b.orderKey[1], N * sizeof(long long), true);
+        ALLOC(b.slabCounters, 8 * sizeof(int), true);
+    }
 #undef ALLOC
     if (rc != FSA_OK) {
         free_all(s);
@@ -333,7 +340,9 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     if (n > 0 && (!pos3 || !vel3 || !type || !mass || !restDensity))
         return fail(FSA_ERR_INVALID, "pos, vel, type, mass and restDensity are required");
     const size_t N = (size_t)n, R = s->real_size();
-    if (uniqueId) {
+    if (s->slab && (color4 || normal3 || group))
+        return fail(FSA_ERR_INVALID, "a slab solver does not store color / normal / group: pass NULL");
+    if (uniqueId && !s->slab) {
         std::vector<unsigned char> seen(N, 0);
         for (size_t i = 0; i < N; i++) {
             const int u = uniqueId[i];
@@ -350,6 +359,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     s->cur = 0;
     invalidate_order(s);
     s->count_valid = false;
+    s->owned_from_sort = false;
     if (n == 0) return FSA_OK;
 
     Staging sp, sv, st, sm;
@@ -368,6 +378,9 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     for (size_t i = 0; i < N; i++) uid[i] = uniqueId ? uniqueId[i] : (int)i;
     FSA_HIP(hipMemcpy(s->b.uniqueId[0], uid.data(), N * sizeof(int), hipMemcpyHostToDevice));
 
+    if (s->slab) {
+        TRY(launch_slab_init_keys(s));
+    }
     // colour, normal and group never change on this path: keep them in uniqueId order
     auto store_static = [&](void *dst, const void *src, size_t elem_bytes) -> int {
         if (!src) {
@@ -380,9 +393,11 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
         FSA_HIP(hipMemcpy(dst, tmp.data(), N * elem_bytes, hipMemcpyHostToDevice));
         return FSA_OK;
     };
-    TRY(store_static(s->b.color, color4, 4 * R));
-    TRY(store_static(s->b.normal, normal3, 3 * R));
-    TRY(store_static(s->b.group, group, sizeof(int)));
+    if (!s->slab) {
+        TRY(store_static(s->b.color, color4, 4 * R));
+        TRY(store_static(s->b.normal, normal3, 3 * R));
+        TRY(store_static(s->b.group, group, sizeof(int)));
+    }
     // start from the zero state the constructor gives
     FSA_HIP(hipMemset(s->b.force, 0, N * 3 * R));
     FSA_HIP(hipMemset(s->b.v_star, 0, N * 3 * R));
@@ -442,6 +457,7 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
     TRY(launch_reorder(s));
     s->cur = 1 - s->cur;
     s->sorted_valid = true;
+    s->owned_from_sort = true;
     s->hash_valid = false;  // hash[] described the previous order
     s->perm_valid = false;
     s->index_table_valid = false;
@@ -514,6 +530,7 @@ int fsa_readback_pos_color(fsa_solver *hs, void *pos3, void *color4, int *n) {
         FSA_HIP(hipStreamSynchronize(s->stream));
         FSA_HIP(hipMemcpy(pos3, st.d, N * 3 * R, hipMemcpyDeviceToHost));
     }
+    if (color4 && s->slab) return fail(FSA_ERR_INVALID, "a slab solver does not store color");
     if (color4) {
         Staging st;
         TRY(st.alloc(N * 4 * R));
@@ -556,6 +573,8 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
         TRY(launch_unpack_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
         return copy_out(s, st.d, dst, bytes);
     }
+    if (s->slab && (k == "color" || k == "normal" || k == "group" || k == "indexTable"))
+        return fail(FSA_ERR_INVALID, "a slab solver does not store '%s' (uniqueId is a global id there)", name);
     if (k == "color" || k == "normal" || k == "group") {
         const size_t words = k == "color" ? 4 * R / 4 : k == "normal" ? 3 * R / 4 : 1;
         TRY(want(N * words * 4));
@@ -571,6 +590,11 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
     if (k == "pressure") { TRY(want(N * R)); return copy_out(s, s->b.pressure, dst, bytes); }
     if (k == "restDensity") { TRY(want(N * R)); return copy_out(s, s->b.restDensity[c], dst, bytes); }
     if (k == "uniqueId") { TRY(want(N * sizeof(int))); return copy_out(s, s->b.uniqueId[c], dst, bytes); }
+    if (k == "orderKey") {
+        if (!s->slab) return fail(FSA_ERR_INVALID, "orderKey exists in slab solvers only");
+        TRY(want(N * sizeof(long long)));
+        return copy_out(s, s->b.orderKey[c], dst, bytes);
+    }
     if (k == "indexTable") {
         TRY(want(N * sizeof(int)));
         if (!s->index_table_valid) {
@@ -584,6 +608,9 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
         if (s->perm_valid) return copy_out(s, s->b.sortedHash, dst, bytes);
         if (s->hash_valid) return copy_out(s, s->b.hash, dst, bytes);
         if (s->sorted_valid) return copy_out(s, s->b.sortedHash, dst, bytes);
+        // after the integration: still the cells of the last sort, as in the reference, where Advect
+        // leaves particleHash alone
+        if (s->owned_from_sort) return copy_out(s, s->b.sortedHash, dst, bytes);
         return fail(FSA_ERR_INVALID, "particleHash is not defined for the current state");
     }
     if (k == "particleIndex") {
@@ -708,6 +735,62 @@ int fsa_timing_read(fsa_solver *hs, fsa_kernel_time *out, int cap, int *count) {
         w++;
     }
     *count = w;
+    return FSA_OK;
+}
+
+// ---- z-slab decomposition ----------------------------------------------------------------------
+int fsa_slab_record_bytes(fsa_solver *hs, int *bytes) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s || !bytes) return fail(FSA_ERR_INVALID, "NULL argument");
+    *bytes = slab_record_bytes(s);
+    return FSA_OK;
+}
+
+int fsa_slab_pack(fsa_solver *hs, const int own[2], const int keep[2], const int left[2], const int right[2],
+                  void *d_send_left, int cap_left, void *d_send_right, int cap_right, int counts[4]) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_pack needs a solver created with slab_nz > 0");
+    if (!own || !keep || !left || !right || !counts) return fail(FSA_ERR_INVALID, "NULL argument");
+    if (cap_left < 0 || cap_right < 0 || (cap_left > 0 && !d_send_left) || (cap_right > 0 && !d_send_right))
+        return fail(FSA_ERR_INVALID, "send buffer missing");
+    // a particle outside [slab_z0, slab_z0 + slab_nz) would hash to GRID_UNDEF at the next sort
+    if (keep[0] < s->pf.z0 || keep[1] > s->pf.z0 + s->pf.nz)
+        return fail(FSA_ERR_INVALID, "keep range [%d, %d) exceeds the layers [%d, %d) this solver holds", keep[0],
+                    keep[1], s->pf.z0, s->pf.z0 + s->pf.nz);
+    TRY(launch_slab_pack(s, own, keep, left, right, d_send_left, cap_left, d_send_right, cap_right, counts));
+    if (counts[0] > s->capacity)
+        return fail(FSA_ERR_CAPACITY, "%d particles stay, capacity %d", counts[0], s->capacity);
+    if (counts[1] > cap_left || counts[2] > cap_right)
+        return fail(FSA_ERR_CAPACITY, "send buffers too small: %d / %d records for %d / %d slots", counts[1],
+                    counts[2], cap_left, cap_right);
+    s->n = counts[0];
+    s->cur = 1 - s->cur;
+    invalidate_order(s);
+    s->count_valid = false;
+    s->owned_from_sort = false;
+    return FSA_OK;
+}
+
+int fsa_slab_unpack(fsa_solver *hs, const void *d_records, int count) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_unpack needs a solver created with slab_nz > 0");
+    if (count < 0 || (count > 0 && !d_records)) return fail(FSA_ERR_INVALID, "bad record buffer");
+    if ((long long)s->n + count > s->capacity)
+        return fail(FSA_ERR_CAPACITY, "%d + %d particles exceed capacity %d", s->n, count, s->capacity);
+    TRY(launch_slab_unpack(s, d_records, count));
+    s->n += count;
+    invalidate_order(s);
+    s->count_valid = false;
+    s->owned_from_sort = false;
+    return FSA_OK;
+}
+
+int fsa_set_scene_has_rigid(fsa_solver *hs, int has_rigid) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
+    s->has_rigid = has_rigid != 0;
     return FSA_OK;
 }
 

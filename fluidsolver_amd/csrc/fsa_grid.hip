@@ -315,6 +315,7 @@ int launch_scatter(Solver *s) {
 
 int launch_rank(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    if (s->slab) return launch_rank_key(s);
     ScopedTimer t(s, "rank");
     hipLaunchKernelGGL(rank_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n, s->b.tmpIndex,
                        s->b.tmpHash, s->b.cellStart, s->b.sortedIndex, s->b.sortedHash);
@@ -337,6 +338,7 @@ int launch_reorder(Solver *s) {
                            (const double *)s->b.restDensity[in], s->b.uniqueId[in], (double4 *)s->b.posType[out],
                            (double4 *)s->b.velMass[out], (double *)s->b.restDensity[out], s->b.uniqueId[out]);
     FSA_HIP(hipGetLastError());
+    if (s->slab) return launch_slab_keys(s);
     return FSA_OK;
 }
 

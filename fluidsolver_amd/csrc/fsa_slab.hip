@@ -1,0 +1,282 @@
+// z-slab decomposition support: one solver per GPU holds the cell layers [z0, z0 + nz) of the global
+// grid (its own layers plus halo layers copied from the neighbouring slabs).  The reference runs on
+// one device only; what has to be preserved is its sorted order -- ascending cell, ties in the order
+// of the previous step's array (solver/sph_solver.cu:46-53 under /root/reference/particle_solver) --
+// because the neighbour sums of DensityCell / ForceCell are accumulated in that order.  A slab only
+// sees part of the previous array, so every particle carries a 64-bit order key
+//     (global cell id at the last sort) << 32 | (rank inside that cell)
+// whose ordering equals the previous global array order; ties inside a cell are broken by it.
+//
+//   slab_pack    after the integration: particles this solver owned at the last sort are classified by
+//                the cell layer they are in now; the ones inside the keep range are compacted into the
+//                other buffer copy, the ones inside a neighbour's range are written as records into
+//                the send buffers (a particle can go to several places: it stays as a halo copy here and
+//                becomes an owned particle there).  Halo copies of the last step are dropped.
+//   slab_unpack  records received from a neighbour are appended.
+//   rank_key     stable rank inside each cell by order key (replaces the by-source-index rank).
+//   slab_keys    new keys after the reorder.
+#include "fsa_solver.h"
+
+namespace fsa {
+
+template <typename T> struct SlabRecord;
+template <> struct SlabRecord<float> {  // 48 bytes
+    float4 posType;
+    float4 velMass;
+    long long orderKey;
+    float restDensity;
+    int uniqueId;
+};
+template <> struct SlabRecord<double> {  // 96 bytes
+    double4 posType;
+    double4 velMass;
+    long long orderKey;
+    double restDensity;
+    int uniqueId;
+    int pad0;
+    long long pad1;
+};
+static_assert(sizeof(SlabRecord<float>) == 48, "record layout");
+static_assert(sizeof(SlabRecord<double>) == 96, "record layout");
+
+int slab_record_bytes(const Solver *s) {
+    return s->precision == FSA_PRECISION_F32 ? (int)sizeof(SlabRecord<float>) : (int)sizeof(SlabRecord<double>);
+}
+
+struct SlabRanges {
+    int own_lo, own_hi;      // layers owned at the last sort
+    int keep_lo, keep_hi;    // layers this solver will hold next (halo included)
+    int left_lo, left_hi;    // layers the left neighbour will hold next
+    int right_lo, right_hi;  // same for the right neighbour
+};
+
+// Slot in one output stream for every lane whose `flag` is set: one atomic per wavefront.
+__device__ __forceinline__ int wave_append(bool flag, int *counter) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return flag ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void slab_pack_kernel(
+    DevParams<T> P, int n, int all_owned, SlabRanges R, const int *__restrict__ sortedHash,
+    const Vec4<T> *__restrict__ posTypeIn, const Vec4<T> *__restrict__ velMassIn, const T *__restrict__ restDensityIn,
+    const int *__restrict__ uniqueIdIn, const long long *__restrict__ keyIn, Vec4<T> *__restrict__ posTypeOut,
+    Vec4<T> *__restrict__ velMassOut, T *__restrict__ restDensityOut, int *__restrict__ uniqueIdOut,
+    long long *__restrict__ keyOut, int capKeep, SlabRecord<T> *__restrict__ sendLeft, int capLeft,
+    SlabRecord<T> *__restrict__ sendRight, int capRight, int *__restrict__ counters) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool keep = false, left = false, right = false, lost = false;
+    Vec4<T> p{};
+    if (i < n) {
+        bool owned = all_owned != 0;
+        if (!owned) {
+            const unsigned h = (unsigned)sortedHash[i];
+            if (h == FSA_GRID_UNDEF) {
+                owned = true;  // halo copies are always inside the grid when they arrive
+            } else {
+                const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
+                owned = gz >= R.own_lo && gz < R.own_hi;
+            }
+        }
+        if (owned) {
+            p = posTypeIn[i];
+            bool inside = in_domain(P, p.x, p.y, p.z);
+            int cx = 0, cy = 0, cz = 0;
+            if (inside) {
+                calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
+                inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
+            }
+            if (!inside) {
+                keep = true;  // out-of-grid particles stay with their owner
+            } else {
+                keep = cz >= R.keep_lo && cz < R.keep_hi;
+                left = cz >= R.left_lo && cz < R.left_hi;
+                right = cz >= R.right_lo && cz < R.right_hi;
+                lost = !keep && !left && !right;
+            }
+        }
+    }
+    const int kslot = wave_append(keep, counters + 0);
+    const int lslot = wave_append(left, counters + 1);
+    const int rslot = wave_append(right, counters + 2);
+    (void)wave_append(lost, counters + 3);
+    if (!(keep || left || right)) return;
+    const Vec4<T> v = velMassIn[i];
+    const T rd = restDensityIn[i];
+    const int uid = uniqueIdIn[i];
+    const long long key = keyIn[i];
+    if (keep && kslot < capKeep) {
+        posTypeOut[kslot] = p;
+        velMassOut[kslot] = v;
+        restDensityOut[kslot] = rd;
+        uniqueIdOut[kslot] = uid;
+        keyOut[kslot] = key;
+    }
+    SlabRecord<T> rec{};
+    rec.posType = p;
+    rec.velMass = v;
+    rec.orderKey = key;
+    rec.restDensity = rd;
+    rec.uniqueId = uid;
+    if (left && lslot < capLeft) sendLeft[lslot] = rec;
+    if (right && rslot < capRight) sendRight[rslot] = rec;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void slab_unpack_kernel(int count, int at, const SlabRecord<T> *__restrict__ recs,
+                                                             Vec4<T> *__restrict__ posType,
+                                                             Vec4<T> *__restrict__ velMass,
+                                                             T *__restrict__ restDensity, int *__restrict__ uniqueId,
+                                                             long long *__restrict__ key) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const SlabRecord<T> r = recs[k];
+    posType[at + k] = r.posType;
+    velMass[at + k] = r.velMass;
+    restDensity[at + k] = r.restDensity;
+    uniqueId[at + k] = r.uniqueId;
+    key[at + k] = r.orderKey;
+}
+
+// Stable rank inside each cell by order key (keys are unique).
+__global__ __launch_bounds__(kBlock) void rank_key_kernel(int n, const int *__restrict__ tmpIndex,
+                                                          const int *__restrict__ tmpHash,
+                                                          const int *__restrict__ cellStart,
+                                                          const long long *__restrict__ key,
+                                                          int *__restrict__ sortedIndex, int *__restrict__ sortedHash) {
+    const int sIdx = blockIdx.x * kBlock + threadIdx.x;
+    if (sIdx >= n) return;
+    const int i = tmpIndex[sIdx];
+    const unsigned h = (unsigned)tmpHash[sIdx];
+    int p = sIdx;
+    if (h != FSA_GRID_UNDEF) {
+        const int a = cellStart[h], b = cellStart[h + 1];
+        const unsigned long long mine = (unsigned long long)key[i];
+        int r = 0;
+        for (int t = a; t < b; t++) {
+            const int j = tmpIndex[t];
+            const unsigned long long other = (unsigned long long)key[j];
+            r += (other < mine || (other == mine && j < i)) ? 1 : 0;
+        }
+        p = a + r;
+    }
+    sortedIndex[p] = i;
+    sortedHash[p] = (int)h;
+}
+
+// key[p] = (global cell id << 32) | rank inside the cell; out-of-grid: (GRID_UNDEF << 32) | rank in the tail
+template <typename T>
+__global__ __launch_bounds__(kBlock) void slab_keys_kernel(DevParams<T> P, int n, const int *__restrict__ sortedHash,
+                                                           const int *__restrict__ cellStart,
+                                                           long long *__restrict__ key) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const unsigned h = (unsigned)sortedHash[p];
+    unsigned long long hi, lo;
+    if (h == FSA_GRID_UNDEF) {
+        hi = FSA_GRID_UNDEF;
+        lo = (unsigned)(p - cellStart[P.num_cells]);
+    } else {
+        const unsigned gx = (unsigned)P.gres[0];
+        const unsigned x = h % gx, t = h / gx;
+        const unsigned lz = t % (unsigned)P.nz, y = t / (unsigned)P.nz;
+        hi = ((unsigned long long)y * (unsigned)P.gres[2] + (lz + (unsigned)P.z0)) * gx + x;
+        lo = (unsigned)(p - cellStart[h]);
+    }
+    key[p] = (long long)((hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(kBlock) void slab_init_keys_kernel(int n, const int *__restrict__ uniqueId,
+                                                                long long *__restrict__ key) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) key[i] = (long long)(unsigned)uniqueId[i];
+}
+
+static inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+int launch_slab_init_keys(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    hipLaunchKernelGGL(slab_init_keys_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                       s->b.uniqueId[s->cur], s->b.orderKey[s->cur]);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_rank_key(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "rank");
+    hipLaunchKernelGGL(rank_key_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n, s->b.tmpIndex,
+                       s->b.tmpHash, s->b.cellStart, s->b.orderKey[s->cur], s->b.sortedIndex, s->b.sortedHash);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// after launch_reorder, before `cur` flips: keys of the new order go to the other copy
+int launch_slab_keys(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "slab_keys");
+    const int out = 1 - s->cur;
+    if (s->precision == FSA_PRECISION_F32)
+        hipLaunchKernelGGL(slab_keys_kernel<float>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->pf, s->n,
+                           s->b.sortedHash, s->b.cellStart, s->b.orderKey[out]);
+    else
+        hipLaunchKernelGGL(slab_keys_kernel<double>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->pd, s->n,
+                           s->b.sortedHash, s->b.cellStart, s->b.orderKey[out]);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+template <typename T>
+static int pack_t(Solver *s, const DevParams<T> &P, const SlabRanges &R, void *sendLeft, int capLeft, void *sendRight,
+                  int capRight) {
+    const int in = s->cur, out = 1 - s->cur;
+    hipLaunchKernelGGL(slab_pack_kernel<T>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, P, s->n,
+                       s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (const Vec4<T> *)s->b.posType[in],
+                       (const Vec4<T> *)s->b.velMass[in], (const T *)s->b.restDensity[in], s->b.uniqueId[in],
+                       s->b.orderKey[in], (Vec4<T> *)s->b.posType[out], (Vec4<T> *)s->b.velMass[out],
+                       (T *)s->b.restDensity[out], s->b.uniqueId[out], s->b.orderKey[out], s->capacity,
+                       (SlabRecord<T> *)sendLeft, capLeft, (SlabRecord<T> *)sendRight, capRight, s->b.slabCounters);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
+                     void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]) {
+    FSA_HIP(hipMemsetAsync(s->b.slabCounters, 0, 4 * sizeof(int), s->stream));
+    if (s->n > 0) {
+        ScopedTimer t(s, "slab_pack");
+        SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1]};
+        int rc = s->precision == FSA_PRECISION_F32
+                     ? pack_t<float>(s, s->pf, R, sendLeft, capLeft, sendRight, capRight)
+                     : pack_t<double>(s, s->pd, R, sendLeft, capLeft, sendRight, capRight);
+        if (rc) return rc;
+    }
+    FSA_HIP(hipMemcpyAsync(counts, s->b.slabCounters, 4 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    return FSA_OK;
+}
+
+int launch_slab_unpack(Solver *s, const void *recs, int count) {
+    if (count == 0) return FSA_OK;
+    ScopedTimer t(s, "slab_unpack");
+    const int c = s->cur;
+    if (s->precision == FSA_PRECISION_F32)
+        hipLaunchKernelGGL(slab_unpack_kernel<float>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, count, s->n,
+                           (const SlabRecord<float> *)recs, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
+                           (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c]);
+    else
+        hipLaunchKernelGGL(slab_unpack_kernel<double>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, count,
+                           s->n, (const SlabRecord<double> *)recs, (double4 *)s->b.posType[c],
+                           (double4 *)s->b.velMass[c], (double *)s->b.restDensity[c], s->b.uniqueId[c],
+                           s->b.orderKey[c]);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+}  // namespace fsa

@@ -47,6 +47,9 @@ struct Buffers {
     void *normal = nullptr;  // 3 reals
     int *group = nullptr;
     int *indexTable = nullptr;
+    // z-slab runs only: order key of every particle (two copies like the hot set), pack counters
+    long long *orderKey[2] = {nullptr, nullptr};
+    int *slabCounters = nullptr;
 };
 
 struct TimedLaunch {
@@ -75,6 +78,8 @@ struct Solver {
     bool count_valid = false;   // cellStart[num_cells] holds the in-grid count of the last sort
     bool ref_cells_valid = false;
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
+    bool slab = false;             // holds a z-slab of the grid: order keys are maintained
+    bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
     int variant = 2;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32
     // timing
     bool timing = false;
@@ -119,6 +124,13 @@ int launch_rigid_volume(Solver *s);
 int launch_density_tuned(Solver *s);
 int launch_force_tuned(Solver *s);
 int debug_time_pass(Solver *s, int which, int ablate, int reps);
+int slab_record_bytes(const Solver *s);
+int launch_slab_init_keys(Solver *s);
+int launch_rank_key(Solver *s);
+int launch_slab_keys(Solver *s);
+int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
+                     void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
+int launch_slab_unpack(Solver *s, const void *recs, int count);
 int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
 int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);
 int launch_unpack_w(Solver *s, const void *src4, void *dst, int n, bool as_int);

@@ -135,6 +135,80 @@ __device__ __forceinline__ float cubic_fast(float d2, float inv_h, float kcubic)
     return (q < 1.0f ? w1 : w2) * kcubic;
 }
 
+// One fluid-fluid pair of the force pass in the fast flavour.  `ok` = the pair counts (inside the
+// support, not the particle itself, a fluid neighbour); a pair that does not count adds exact zeros.
+__device__ __forceinline__ void force_pair_fast(ForceSelf<float> &S, float sr, float kspiky, float visc_eps,
+                                                float xx, float xy, float xz, float d2, bool ok, const float4 &vj,
+                                                const float2 &aj) {
+    const float rinv = __builtin_amdgcn_rsqf(d2);
+    const float c = sr - d2 * rinv;
+    const float nablaw = kspiky * c * c * rinv;
+    const float pc = ok ? nablaw * vj.w * (aj.x + S.pterm) : 0.0f;
+    const float vc = ok ? nablaw * d2 * __builtin_amdgcn_rcpf(d2 + visc_eps) * aj.y : 0.0f;
+    S.fx = __builtin_fmaf(-xx, pc, S.fx);
+    S.fy = __builtin_fmaf(-xy, pc, S.fy);
+    S.fz = __builtin_fmaf(-xz, pc, S.fz);
+    S.fx = __builtin_fmaf(S.v.x - vj.x, vc, S.fx);
+    S.fy = __builtin_fmaf(S.v.y - vj.y, vc, S.fy);
+    S.fz = __builtin_fmaf(S.v.z - vj.z, vc, S.fz);
+}
+
+// Per-particle walks in the fast flavour, for blocks that cannot use the row tiles.  They evaluate the
+// same expressions in the same order as the tiled kernels, so a particle's result does not depend on
+// which path its block took (nor, in a slab run, on how the particles are split over solvers).
+__device__ __forceinline__ float density_walk_global_fast(const DevParams<float> &P, const float4 &pi, float mass_i,
+                                                          const float4 *__restrict__ posType,
+                                                          const int *__restrict__ cellStart) {
+    const float sr = P.sr, sr2 = sr * sr;
+    const float h = (float)((double)sr * 0.5);
+    const float inv_h = 1.0f / h, kcubic = P.kernel_cubic;
+    const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
+    float dens = 0.f;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const float4 pj = posType[j];
+                if (unpack_int(pj.w) != FSA_TYPE_FLUID) continue;
+                const float xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                if (d2 < sr2) dens = __builtin_fmaf(mass_i, cubic_fast(d2, inv_h, kcubic), dens);
+            }
+        }
+    return dens;
+}
+
+// S collects the fluid neighbours, Sb the TYPE_BOUNDARY ones (exact arithmetic, summed separately).
+__device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P, int index, ForceSelf<float> &S,
+                                                       ForceSelf<float> &Sb, const float4 *__restrict__ posType,
+                                                       const float4 *__restrict__ velMass,
+                                                       const float2 *__restrict__ pd,
+                                                       const int *__restrict__ cellStart) {
+    const float sr = P.sr, sr2 = sr * sr;
+    const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+    const RowWalk<float> walk(P, S.p.x, S.p.y, S.p.z);
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const float4 pj = posType[j];
+                const int tj = unpack_int(pj.w);
+                const float xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
+                if (tj == FSA_TYPE_FLUID) {
+                    const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                    if (d2 < sr2 && j != index)
+                        force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, true, velMass[j], pd[j]);
+                } else {
+                    const float d2 = xx * xx + xy * xy + xz * xz;
+                    if (force_pair_active(tj, j == index, d2, sr2))
+                        force_pair(P, sr, sr2, Sb, j == index, pj, velMass[j], pd[j].x, 1.0f);
+                }
+            }
+        }
+}
+
 static int g_ablate = 0;        // timing experiments only (debug_time_pass)
 static void *g_out0 = nullptr;  // when set, results go to these scratch arrays instead
 static void *g_out1 = nullptr;
@@ -172,7 +246,8 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     float dens = 0.f;
     if (!staged) {
         if (active && !(ablate & 32))
-            dens = density_walk_global(P, index, pi, mass_i, rd_i, posType, restDensity, cellStart);
+            dens = FAST ? density_walk_global_fast(P, pi, mass_i, posType, cellStart)
+                        : density_walk_global(P, index, pi, mass_i, rd_i, posType, restDensity, cellStart);
     } else {
         const float sr = P.sr, sr2 = sr * sr;
         const float h = (float)((double)sr * 0.5);
@@ -328,9 +403,16 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
         S.pterm = pd[index].x;
     }
     const float sr = P.sr, sr2 = sr * sr;
+    // FAST: wall neighbours are summed on their own (Sb) and added at the end, so the result does not
+    // depend on how the queue happened to be cut into batches
+    ForceSelf<float> Sb = S;
     if (!staged) {
-        if (active && !(ablate & 32))
-            force_walk_global(P, index, S, posType, velMass, density, pressure, cellStart);
+        if (active && !(ablate & 32)) {
+            if (FAST)
+                force_walk_global_fast(P, index, S, Sb, posType, velMass, pd, cellStart);
+            else
+                force_walk_global(P, index, S, posType, velMass, density, pressure, cellStart);
+        }
     } else {
         const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
         const float sr2c = FAST ? sr2 : sr2 * 1.000002f;  // the unfused test of EXACT comes later
@@ -344,7 +426,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
             const float xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
             const float d2 = xx * xx + xy * xy + xz * xz;
             if (force_pair_active(unpack_int(pj.w), j == index, d2, sr2))
-                force_pair(P, sr, sr2, S, j == index, pj, vj, aj.x, FAST ? 1.0f : aj.y);
+                force_pair(P, sr, sr2, FAST ? Sb : S, j == index, pj, vj, aj.x, FAST ? 1.0f : aj.y);
         };
         // One batch of the drain: DB neighbours whose loads are issued together.
         struct Batch {
@@ -377,17 +459,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                     const int tj = unpack_int(B.pj[u].w);
                     const bool ok = d2 < sr2 && B.j[u] != index && tj == FSA_TYPE_FLUID;
                     other |= tj != FSA_TYPE_FLUID && s + u < cnt;
-                    const float rinv = __builtin_amdgcn_rsqf(d2);
-                    const float c = sr - d2 * rinv;
-                    const float nablaw = kspiky * c * c * rinv;
-                    const float pc = ok ? nablaw * B.vj[u].w * (B.aj[u].x + S.pterm) : 0.0f;
-                    const float vc = ok ? nablaw * d2 * __builtin_amdgcn_rcpf(d2 + visc_eps) * B.aj[u].y : 0.0f;
-                    S.fx = __builtin_fmaf(-xx, pc, S.fx);
-                    S.fy = __builtin_fmaf(-xy, pc, S.fy);
-                    S.fz = __builtin_fmaf(-xz, pc, S.fz);
-                    S.fx = __builtin_fmaf(S.v.x - B.vj[u].x, vc, S.fx);
-                    S.fy = __builtin_fmaf(S.v.y - B.vj[u].y, vc, S.fy);
-                    S.fz = __builtin_fmaf(S.v.z - B.vj[u].z, vc, S.fz);
+                    force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, ok, B.vj[u], B.aj[u]);
                 }
                 if (wave_any(other)) {  // wall particles among them (rare)
 #pragma unroll
@@ -489,6 +561,11 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     if (active) {
         Vec3<float> f;
+        if (FAST) {
+            S.fx += Sb.fx;
+            S.fy += Sb.fy;
+            S.fz += Sb.fz;
+        }
         f.x = S.fx + 0.0f;
         f.y = S.fy + (float)-9.8;  // the literal of solver/sph_kernel_impl.cuh:372
         f.z = S.fz + 0.0f;

@@ -1,0 +1,369 @@
+"""z-slab decomposition of the particle step over the GPUs of one node.
+
+The reference (/root/reference/particle_solver) runs SPHSolver::SolveSPH (solver/sph_solver.cpp:87-98)
+on one device.  Here the uniform grid is cut along z into slabs of whole cell layers, one process and
+one solver per GPU.  A slab holds its own layers plus `halo` layers on each side that mirror the
+neighbouring slabs; with halo = 2 the density of every particle within one cell of an owned particle is
+computed locally from complete neighbourhoods, so one exchange per step is enough:
+
+    after the integration each rank sends, to each z-neighbour, the particles it owned whose new cell
+    layer lies inside the layers that neighbour holds (new owners and fresh halo copies alike), drops
+    its old halo copies, and appends what it receives (fsa_slab_pack / fsa_slab_unpack), then runs the
+    ordinary sort -> density -> force -> integration on its local set.
+
+The records travel with torch.distributed point-to-point calls: RCCL over xGMI when the backend is
+"nccl" (device buffers are handed to it directly), host staging when it is "gloo".  Because ties inside a
+cell are broken by the order key each particle carries, a slab run gives, for every owned particle,
+bit-for-bit the numbers of the single-device run.
+
+Layer ownership is fixed for a run: the cuts balance the initial per-layer particle histogram.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+HALO = 2
+
+
+# ------------------------------------------------------------------------------------------------
+# layout
+# ------------------------------------------------------------------------------------------------
+def cell_layer_host(pos, vmin, vmax, dx, gridres):
+    """Global cell layer (z index) of each position with the arithmetic of calcGridPos / calcHashD
+    (solver/sph_kernel_impl.cuh:74-100): fp32 subtract, divide, floor; -1 outside the domain."""
+    pos = np.asarray(pos)
+    dt = pos.dtype.type
+    inside = np.ones(len(pos), bool)
+    for a in range(3):
+        x = pos[:, a].astype(np.float64)
+        inside &= (x < float(dt(vmax[a])) - 1e-10) & (x > float(dt(vmin[a])) + 1e-10)
+    cell = [np.floor((pos[:, a] - dt(vmin[a])) / dt(dx)).astype(np.int64) for a in range(3)]
+    for a in range(3):
+        inside &= (cell[a] >= 0) & (cell[a] < gridres[a])
+    return np.where(inside, cell[2], -1)
+
+
+def balanced_cuts(layer_counts, nranks, min_layers=HALO + 1):
+    """Cut indices c[0..nranks] (c[0] = 0, c[-1] = number of layers) that balance the particle counts,
+    every slab at least `min_layers` thick."""
+    gz = len(layer_counts)
+    if gz < nranks * min_layers:
+        raise ValueError(f"{gz} cell layers cannot be cut into {nranks} slabs of at least {min_layers}")
+    pre = np.concatenate([[0], np.cumsum(layer_counts)]).astype(np.float64)
+    total = pre[-1]
+    cuts = [0]
+    for r in range(1, nranks):
+        target = total * r / nranks
+        c = int(np.searchsorted(pre, target, side="left"))
+        # the nearer of the two candidate layer boundaries
+        if c > 0 and abs(pre[c - 1] - target) <= abs(pre[min(c, gz)] - target):
+            c -= 1
+        c = max(c, cuts[-1] + min_layers)
+        c = min(c, gz - (nranks - r) * min_layers)
+        cuts.append(c)
+    cuts.append(gz)
+    return cuts
+
+
+class SlabLayout:
+    def __init__(self, gz, cuts, halo=HALO):
+        self.gz, self.cuts, self.halo = int(gz), [int(c) for c in cuts], int(halo)
+        self.world = len(cuts) - 1
+
+    def own(self, r):
+        return (self.cuts[r], self.cuts[r + 1])
+
+    def held(self, r):
+        """layers a rank holds: its own plus the halo, clipped to the grid; empty for r outside the ranks"""
+        if r < 0 or r >= self.world:
+            return (0, 0)
+        return (max(self.cuts[r] - self.halo, 0), min(self.cuts[r + 1] + self.halo, self.gz))
+
+
+# ------------------------------------------------------------------------------------------------
+# transport
+# ------------------------------------------------------------------------------------------------
+class NeighbourTransport:
+    """Record exchange with the two z-neighbours over torch.distributed point-to-point calls."""
+
+    def __init__(self, rank, world, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.backend = dist.get_backend(group)
+        # RCCL moves device memory itself; gloo needs host tensors
+        self.staged = self.backend != "nccl" or device.type != "cuda"
+        self.comm_device = torch.device("cpu") if self.staged else device
+
+    def _batch(self, sends, recvs):
+        dist = self.dist
+        ops = [dist.P2POp(dist.irecv, t, peer, self.group) for peer, t in recvs]
+        ops += [dist.P2POp(dist.isend, t, peer, self.group) for peer, t in sends]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def exchange(self, send, recv_bufs, record_bytes):
+        """send = {peer: (uint8 tensor, count)}; recv_bufs = {peer: uint8 tensor}; returns {peer: count}.
+        Received records are in recv_bufs[peer][:count * record_bytes] when this returns (for device
+        buffers: stream-ordered on the current stream)."""
+        torch = self.torch
+        peers = sorted(send)
+        out_cnt = {p: torch.tensor([send[p][1]], dtype=torch.int64, device=self.comm_device) for p in peers}
+        in_cnt = {p: torch.zeros(1, dtype=torch.int64, device=self.comm_device) for p in peers}
+        self._batch([(p, out_cnt[p]) for p in peers], [(p, in_cnt[p]) for p in peers])
+        counts = {p: int(in_cnt[p].item()) for p in peers}
+        sends, recvs, staged_in = [], [], {}
+        for p in peers:
+            nb = send[p][1] * record_bytes
+            if nb:
+                t = send[p][0][:nb]
+                sends.append((p, t.cpu() if self.staged else t))
+            nb = counts[p] * record_bytes
+            if nb > recv_bufs[p].numel():
+                raise RuntimeError(f"rank {self.rank}: {counts[p]} records from rank {p} exceed the receive buffer")
+            if nb:
+                if self.staged:
+                    staged_in[p] = torch.empty(nb, dtype=torch.uint8)
+                    recvs.append((p, staged_in[p]))
+                else:
+                    recvs.append((p, recv_bufs[p][:nb]))
+        self._batch(sends, recvs)
+        for p, t in staged_in.items():
+            recv_bufs[p][:t.numel()].copy_(t)
+        return counts
+
+
+# ------------------------------------------------------------------------------------------------
+# local solver on the GPU
+# ------------------------------------------------------------------------------------------------
+class HipSlabBackend:
+    """The slab's particles in one fsa_solver on a GPU; all work goes through the C ABI."""
+
+    def __init__(self, params_dict, held, capacity, device_index, variant=None):
+        import torch
+        from . import capi
+        self.torch, self.capi = torch, capi
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        p = capi.make_params(capi.PRECISION_F32, **params_dict, slab_z0=held[0], slab_nz=held[1] - held[0])
+        self.params = p
+        self.solver = capi.Solver(p, capacity, device=device_index)
+        # one torch stream carries the solver's kernels, the staging copies and (through torch's stream
+        # semantics) the RCCL calls, so packing, transfer and unpacking are ordered without host syncs
+        self.stream = torch.cuda.Stream(self.device)
+        self.solver.set_stream(self.stream.cuda_stream)
+        if variant is not None:
+            self.solver.set_variant(variant)
+        self.record_bytes = self.solver.slab_record_bytes
+
+    def make_buffer(self, records):
+        return self.torch.empty(max(records, 1) * self.record_bytes, dtype=self.torch.uint8, device=self.device)
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def upload(self, sub):
+        self.solver.upload(sub)
+
+    def set_scene_has_rigid(self, flag):
+        self.solver.set_scene_has_rigid(flag)
+
+    def pack(self, own, keep, left, right, buf_left, cap_left, buf_right, cap_right):
+        return self.solver.slab_pack(own, keep, left, right, buf_left.data_ptr(), cap_left, buf_right.data_ptr(),
+                                     cap_right)
+
+    def unpack(self, buf, count):
+        self.solver.slab_unpack(buf.data_ptr(), count)
+
+    def step_local(self):
+        self.solver.step(1)
+
+    def synchronize(self):
+        self.solver.synchronize()
+
+    @property
+    def n(self):
+        return self.solver.n
+
+    def get(self, name):
+        return self.solver.get(name)
+
+    def global_layer_of_sorted(self):
+        """global cell layer of each local particle from the sorted hashes (-1: out of grid)"""
+        h = self.solver.get("particleHash").astype(np.int64)
+        gx, nz, z0 = self.params.gridres[0], self.params.slab_nz, self.params.slab_z0
+        return np.where(h == self.capi.GRID_UNDEF, -1, (h // gx) % nz + z0)
+
+    def close(self):
+        self.solver.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the distributed solver
+# ------------------------------------------------------------------------------------------------
+class SlabSolver:
+    """One rank's share of a scene.  `backend_factory(params_dict, held, capacity)` builds the local
+    solver (HipSlabBackend on a GPU); `transport` moves records between ranks."""
+
+    def __init__(self, scene, rank, world, transport, backend_factory, halo=HALO, slack=1.5, cuts=None):
+        P = scene["params"]
+        self.rank, self.world, self.transport = rank, world, transport
+        pos = np.asarray(scene["pos"], dtype=np.float32)
+        # grid geometry exactly as the solver derives it
+        geo = derive_grid(P)
+        self.gridres, self.dx = geo["gridres"], geo["dx"]
+        gz = self.gridres[2]
+        layer = cell_layer_host(pos, geo["vmin"], geo["vmax"], self.dx, self.gridres)
+        hist = np.bincount(layer[layer >= 0], minlength=gz)
+        if cuts is None:
+            cuts = balanced_cuts(hist, world, halo + 1) if world > 1 else [0, gz]
+        self.layout = SlabLayout(gz, cuts, halo)
+        own, held = self.layout.own(rank), self.layout.held(rank)
+        self.own, self.held_layers = own, held
+        # out-of-grid particles start on rank 0
+        mine = (layer >= own[0]) & (layer < own[1])
+        if rank == 0:
+            mine |= layer < 0
+        pre = np.concatenate([[0], np.cumsum(hist)])
+        held_counts = [pre[self.layout.held(r)[1]] - pre[self.layout.held(r)[0]] for r in range(world)]
+        n_outside = int((layer < 0).sum())
+        self.capacity = int(max(held_counts) * slack) + n_outside + 4096
+        widest = max(int(hist[max(c - 2 * halo, 0):c + 2 * halo].sum()) for c in self.layout.cuts[1:-1]) \
+            if world > 1 else 0
+        self.record_cap = int(widest * slack) + 4096
+        self.backend = backend_factory(P, held, self.capacity)
+        uid = np.asarray(scene.get("uniqueId", np.arange(len(pos))), dtype=np.int32)
+        sub = {k: np.ascontiguousarray(np.asarray(scene[k])[mine]) for k in ("pos", "vel", "type", "mass",
+                                                                             "restDensity")}
+        sub["uniqueId"] = np.ascontiguousarray(uid[mine])
+        self.backend.upload(sub)
+        self.backend.set_scene_has_rigid(bool((np.asarray(scene["type"]) == 4).any()))
+        self.peers = [p for p in (rank - 1, rank + 1) if 0 <= p < world]
+        self.send_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
+        self.recv_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
+        self._null = self.backend.make_buffer(1)
+        self.lost = 0
+        self.sent_records = 0
+        self.exchange_seconds = 0.0
+
+    def exchange(self):
+        """migration and halo refresh in one neighbour exchange"""
+        r, lay = self.rank, self.layout
+        left, right = lay.held(r - 1), lay.held(r + 1)
+        bl = self.send_buf.get(r - 1, self._null)
+        br = self.send_buf.get(r + 1, self._null)
+        cl = self.record_cap if r - 1 in self.send_buf else 0
+        cr = self.record_cap if r + 1 in self.send_buf else 0
+        kept, nl, nr, lost = self.backend.pack(self.own, self.held_layers, left, right, bl, cl, br, cr)
+        self.lost += lost
+        send = {}
+        if r - 1 in self.send_buf:
+            send[r - 1] = (bl, nl)
+        if r + 1 in self.send_buf:
+            send[r + 1] = (br, nr)
+        if send:
+            got = self.transport.exchange(send, self.recv_buf, self.backend.record_bytes)
+            for p in self.peers:  # fixed order: left neighbour first
+                self.backend.unpack(self.recv_buf[p], got[p])
+        self.sent_records += nl + nr
+
+    def step(self, nsteps=1):
+        with self.backend.stream_ctx():
+            for _ in range(nsteps):
+                self.exchange()
+                self.backend.step_local()
+
+    def owned(self):
+        """Results of the last step for the particles this rank owned during it, as host arrays."""
+        b = self.backend
+        layer = b.global_layer_of_sorted()
+        m = ((layer >= self.own[0]) & (layer < self.own[1])) | (layer < 0)
+        out = {k: b.get(k)[m] for k in ("pos", "vel", "density", "pressure", "force", "uniqueId", "type")}
+        out["hash_layer"] = layer[m]
+        return out
+
+    def close(self):
+        self.backend.close()
+
+
+def derive_grid(P):
+    """Grid box, cell size and resolution as MultiphaseSPHSolver::LoadParam derives them in fp32
+    (solver/MultiphaseSPHSolver.cpp:381, 452-466); computed by the library's fsa_derive_params."""
+    from . import capi
+    p = capi.make_params(capi.PRECISION_F32, **P)
+    return {"dx": np.float32(p.dx), "vmin": [np.float32(v) for v in p.gridxmin],
+            "vmax": [np.float32(v) for v in p.gridxmax], "gridres": [int(v) for v in p.gridres]}
+
+
+# ------------------------------------------------------------------------------------------------
+# bench entry (bench.py --gpus N under torch.distributed.run)
+# ------------------------------------------------------------------------------------------------
+def bench_distributed(args, build_scene):
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    ndev = torch.cuda.device_count()
+    assert ndev > 0, "bench.py needs a GPU"
+    device_index = local % ndev
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
+    # RCCL needs one GPU per rank; ranks sharing a card (rehearsal on a one-GPU box) go through gloo
+    backend = "nccl" if ndev >= world else "gloo"
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    sc = build_scene(args.scene, args.jitter)
+    n, n_fluid = len(sc["pos"]), sc["n_fluid"]
+    transport = NeighbourTransport(rank, world, device)
+    ss = SlabSolver(sc, rank, world, transport,
+                    lambda P, held, cap: HipSlabBackend(P, held, cap, device_index, args.variant))
+    sync_dev = device if backend == "nccl" else torch.device("cpu")
+
+    def barrier():
+        torch.cuda.synchronize()
+        t = torch.zeros(1, device=sync_dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+
+    ss.step(args.spinup)
+    ss.step(args.warmup)
+    ss.backend.solver.timing_enable(True)
+    ss.backend.solver.timing_reset()
+    sent0 = ss.sent_records
+    barrier()
+    t0 = time.perf_counter()
+    ss.step(args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    kt = ss.backend.solver.timing_read()
+    ss.backend.solver.timing_enable(False)
+    local_n = ss.backend.n
+    types = ss.backend.get("type")
+    local_fluid = int((types == 0).sum())
+    stats = torch.tensor([wall, float(local_n), float(ss.lost), float(ss.backend.solver.num_undef()),
+                          float(ss.sent_records - sent0)], dtype=torch.float64, device=sync_dev)
+    mx = stats.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = stats.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    res = dict(n=n, n_fluid=n_fluid, wall=float(mx[0]), kernels=kt, num_cells=ss.backend.params.num_cells,
+               n_undef=int(sm[3]), gridres=list(ss.gridres), local_n=local_n, local_n_fluid=local_fluid,
+               slab_cuts=ss.layout.cuts, halo_layers=ss.layout.halo, max_local_particles=int(mx[1]),
+               sum_local_particles=int(sm[1]), lost_particles=int(sm[2]),
+               records_sent_per_step=float(sm[4]) / max(args.steps, 1), comm_backend=backend)
+    ss.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return res

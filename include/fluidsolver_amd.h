@@ -170,7 +170,8 @@ int fsa_readback_pos_color(fsa_solver *s, void *pos3, void *color4, int *n);
  * uniqueId indexTable particleHash particleIndex (n ints); gridCellStart
  * gridCellEnd (num_cells ints; gridCellEnd is only meaningful where
  * gridCellStart != 0xffffffff, as in the reference); cellStartDense
- * (num_cells + 1 ints, exclusive prefix of the per-cell counts).
+ * (num_cells + 1 ints, exclusive prefix of the per-cell counts); orderKey (n 64-bit ints, slab
+ * solvers only).
  * `bytes` must be the exact size.  Both synchronise.
  */
 int fsa_get_buffer(fsa_solver *s, const char *name, void *dst, size_t bytes);
@@ -197,6 +198,45 @@ int fsa_timing_read(fsa_solver *s, fsa_kernel_time *out, int cap, int *count);
  *   2  tuned structure, fast fp32 arithmetic (hardware sqrt/rsq/rcp, fused multiply-adds): about
  *      1e-7 relative away from variant 1 per neighbour term.  Default. */
 int fsa_set_variant(fsa_solver *s, int variant);
+
+/* ---- z-slab decomposition: one solver per GPU ---------------------------
+ *
+ * The reference runs on one device; these entry points have no counterpart in it.  They split the
+ * step of SPHSolver::SolveSPH (solver/sph_solver.cpp:87-98) over several solvers, each created with
+ * fsa_params.slab_z0 / slab_nz naming the global cell layers it holds (its own layers plus halo
+ * layers that mirror the neighbouring slabs), so that every solver reproduces, for the particles it
+ * owns, exactly the neighbour sums the single-device run computes: ties inside a cell are broken by a
+ * 64-bit order key (global cell at the last sort, rank inside that cell) that travels with each
+ * particle and orders particles as the previous step's global array did.  Before the first sort the
+ * key is the particle's uniqueId, so a slab run matches a single-device run whose uniqueId is
+ * 0..n-1 in upload order.
+ *
+ * A slab solver does not store color / normal / group / indexTable (uniqueId is a global id there):
+ * fsa_upload wants NULL for them and skips the permutation check.  The order of out-of-grid particles
+ * at the tail of the arrays is unspecified in a slab run.
+ *
+ * Per step, between fsa_advect and the next fsa_calc_hash:
+ *   fsa_slab_pack    -> send the two record buffers to the neighbours (RCCL send/recv, the caller's job)
+ *   fsa_slab_unpack  for each buffer received.
+ */
+/* Size of one exchange record: 48 bytes (fp32) / 96 bytes (fp64). */
+int fsa_slab_record_bytes(fsa_solver *s, int *bytes);
+/*
+ * Classifies the particles this solver OWNED at the last sort (cell layer in [own[0], own[1]) then, or
+ * outside the grid; all particles if no sort has run since the upload) by the cell layer they are in
+ * now.  Those in [keep[0], keep[1]) -- and those outside the grid -- remain; those in
+ * [left[0], left[1]) / [right[0], right[1]) are written as records to the device buffers
+ * d_send_left / d_send_right (cap_* records each); a particle may do several of these.  Everything
+ * else the solver held (last step's halo copies) is dropped.  counts = {remaining, records left,
+ * records right, lost}: `lost` counts owned particles that fit none of the ranges.  Synchronises.
+ */
+int fsa_slab_pack(fsa_solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
+                  void *d_send_left, int cap_left, void *d_send_right, int cap_right, int counts[4]);
+/* Appends `count` records from device memory (written by a neighbour's fsa_slab_pack). */
+int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
+/* Overrides the scan of `type` that fsa_upload does: whether a TYPE_RIGID particle can ever be held by
+ * this solver (in a slab run one may arrive from a neighbour later). */
+int fsa_set_scene_has_rigid(fsa_solver *s, int has_rigid);
 
 #ifdef __cplusplus
 }

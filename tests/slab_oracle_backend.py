@@ -1,0 +1,152 @@
+"""CPU stand-in for the per-GPU solver of fluidsolver_amd.slabs, built on the oracle.
+
+Test infrastructure: lets the slab driver (layout, neighbour exchange, ownership rules) run under gloo
+without a GPU.  It restates fsa_slab_pack / fsa_slab_unpack and the order-key tie break in numpy.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+GRID_UNDEF = 99999999
+RECORD = np.dtype([("posType", "<f4", 4), ("velMass", "<f4", 4), ("orderKey", "<i8"), ("restDensity", "<f4"),
+                   ("uniqueId", "<i4")])
+assert RECORD.itemsize == 48
+
+
+class OracleSlabBackend:
+    record_bytes = RECORD.itemsize
+
+    def __init__(self, orc, params_dict, held, capacity):
+        self.orc = orc
+        P = params_dict
+        self.p = orc.make_params(P["spacing"], P["smoothratio"], P["vmin"], P["vmax"], gravity=P["gravity"],
+                                 dt=P["dt"], viscosity=P["viscosity"], pressureK=P["pressureK"],
+                                 boundary_visc=P["boundary_visc"], acceleration_limit=P["acceleration_limit"],
+                                 boundary_mode=P["boundary_mode"])
+        self.gres = [int(v) for v in self.p.gridres]
+        self.num_cells = self.gres[0] * self.gres[1] * self.gres[2]
+        self.held, self.capacity = held, capacity
+        self.a = {}
+        self.key = np.zeros(0, np.int64)
+        self.sorted_hash = None
+        self.res = {}
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def make_buffer(self, records):
+        return torch.empty(max(records, 1) * self.record_bytes, dtype=torch.uint8)
+
+    def stream_ctx(self):
+        return contextlib.nullcontext()
+
+    def set_scene_has_rigid(self, flag):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass
+
+    @property
+    def n(self):
+        return len(self.key)
+
+    def upload(self, sub):
+        self.a = {"pos": np.array(sub["pos"], np.float32).reshape(-1, 3),
+                  "vel": np.array(sub["vel"], np.float32).reshape(-1, 3),
+                  "type": np.array(sub["type"], np.int32), "mass": np.array(sub["mass"], np.float32),
+                  "restDensity": np.array(sub["restDensity"], np.float32),
+                  "uniqueId": np.array(sub["uniqueId"], np.int32)}
+        self.key = self.a["uniqueId"].astype(np.int64)
+        self.sorted_hash = None
+
+    def _state(self):
+        # the oracle indexes indexTable with uniqueId, so it gets local ids; the global ones stay here
+        st = self.orc.new_state(self.n, self.num_cells)
+        st.load({k: self.a[k] for k in ("pos", "vel", "type", "mass", "restDensity")})
+        return st
+
+    def _layer_of_hash(self, h):
+        h = h.astype(np.int64)
+        return np.where(h == GRID_UNDEF, -1, (h // self.gres[0]) % self.gres[2])
+
+    # -- exchange ---------------------------------------------------------------------------------
+    def pack(self, own, keep, left, right, buf_left, cap_left, buf_right, cap_right):
+        n = self.n
+        if self.sorted_hash is None:
+            owned = np.ones(n, bool)
+        else:
+            was = self._layer_of_hash(self.sorted_hash)
+            owned = (was < 0) | ((was >= own[0]) & (was < own[1]))
+        st = self._state()
+        st.calc_hash(self.p)
+        now = self._layer_of_hash(st["particleHash"].copy())
+        st.close()
+        inside = now >= 0
+        k = owned & (~inside | ((now >= keep[0]) & (now < keep[1])))
+        l = owned & inside & (now >= left[0]) & (now < left[1])
+        r = owned & inside & (now >= right[0]) & (now < right[1])
+        lost = owned & inside & ~k & ~l & ~r
+        for mask, buf, cap in ((l, buf_left, cap_left), (r, buf_right, cap_right)):
+            m = int(mask.sum())
+            assert m <= cap, "send buffer too small"
+            rec = np.zeros(m, RECORD)
+            rec["posType"][:, :3] = self.a["pos"][mask]
+            rec["posType"][:, 3] = self.a["type"][mask].view(np.float32)
+            rec["velMass"][:, :3] = self.a["vel"][mask]
+            rec["velMass"][:, 3] = self.a["mass"][mask]
+            rec["orderKey"] = self.key[mask]
+            rec["restDensity"] = self.a["restDensity"][mask]
+            rec["uniqueId"] = self.a["uniqueId"][mask]
+            if m:
+                buf.numpy()[:m * RECORD.itemsize] = rec.view(np.uint8).reshape(-1)
+        self.a = {name: v[k] for name, v in self.a.items()}
+        self.key = self.key[k]
+        self.sorted_hash = None
+        return int(k.sum()), int(l.sum()), int(r.sum()), int(lost.sum())
+
+    def unpack(self, buf, count):
+        if count == 0:
+            return
+        rec = buf.numpy()[:count * RECORD.itemsize].view(RECORD)
+        add = {"pos": rec["posType"][:, :3], "type": np.ascontiguousarray(rec["posType"][:, 3]).view(np.int32),
+               "vel": rec["velMass"][:, :3], "mass": rec["velMass"][:, 3], "restDensity": rec["restDensity"],
+               "uniqueId": rec["uniqueId"]}
+        self.a = {name: np.concatenate([v, add[name]]) for name, v in self.a.items()}
+        self.key = np.concatenate([self.key, rec["orderKey"]])
+
+    # -- one step ---------------------------------------------------------------------------------
+    def step_local(self):
+        # the oracle's sort is stable in array order: put the array in key order first
+        order = np.argsort(self.key.astype(np.uint64), kind="stable")
+        self.a = {name: v[order] for name, v in self.a.items()}
+        st = self._state()
+        st.sort_particles(self.p)
+        h = st["particleHash"].copy()
+        st.compute_pressure(self.p)
+        st.compute_force(self.p)
+        self.res = {k: st[k].copy() for k in ("density", "pressure", "force")}
+        st.advect(self.p)
+        local = st["uniqueId"].copy()
+        for k in ("pos", "vel", "type", "mass", "restDensity"):
+            self.a[k] = st[k].copy()
+        self.a["uniqueId"] = self.a["uniqueId"][local]
+        st.close()
+        # new keys: (global cell, rank inside the cell); the oracle holds the whole grid, so h is global
+        n = len(h)
+        first = np.ones(n, bool)
+        first[1:] = h[1:] != h[:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(n), 0))
+        self.key = (h.astype(np.int64) << 32) | (np.arange(n) - start)
+        self.sorted_hash = h
+
+    def get(self, name):
+        if name in self.res:
+            return self.res[name]
+        if name == "particleHash":
+            return self.sorted_hash
+        return self.a[name]
+
+    def global_layer_of_sorted(self):
+        return self._layer_of_hash(self.sorted_hash)

@@ -1,0 +1,69 @@
+"""One rank of a slab run, started by the slab tests as a separate process:
+
+    python tests/slab_worker.py --rank R --world N --port P --out DIR --backend oracle|hip --steps K
+
+Writes DIR/rank<R>.npz with the results for the particles the rank owns.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def test_scene():
+    """small dam break with noise on positions and velocities: particles cross the slab cuts"""
+    from fluidsolver_amd import scenes
+    sc = scenes.dam_break(12, 10, 28)
+    n_fluid = sc["n_fluid"]
+    sc = scenes.jittered(sc, seed=77, pos_jitter=0.2, vel_scale=1.5, fluid_only=True)
+    sc["n_fluid"] = n_fluid
+    return sc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--backend", choices=["oracle", "hip"], required=True)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--variant", type=int, default=2)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fluidsolver_amd import slabs
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
+    sc = test_scene()
+    if a.backend == "oracle":
+        from oracle.orc import Oracle
+        from slab_oracle_backend import OracleSlabBackend
+        orc = Oracle("f32")
+        orc.set_threads(2)
+        device = torch.device("cpu")
+        factory = lambda P, held, cap: OracleSlabBackend(orc, P, held, cap)  # noqa: E731
+    else:
+        device = torch.device("cuda", 0)
+        factory = lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, a.variant)  # noqa: E731
+    tr = slabs.NeighbourTransport(a.rank, a.world, device)
+    ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory)
+    ss.step(a.steps)
+    out = ss.owned()
+    out["cuts"] = np.asarray(ss.layout.cuts)
+    out["lost"] = np.asarray(ss.lost)
+    out["sent"] = np.asarray(ss.sent_records)
+    np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **out)
+    ss.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
