@@ -50,17 +50,7 @@ struct SlabRanges {
     int right_lo, right_hi;  // same for the right neighbour
 };
 
-// Slot in one output stream for every lane whose `flag` is set: one atomic per wavefront.
-__device__ __forceinline__ int wave_append(bool flag, int *counter) {
-    const unsigned long long m = __ballot(flag);
-    if (m == 0) return -1;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader, 64);
-    return flag ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-}
+constexpr int kPackItems = 4;  // particles per thread: one atomic per stream for 1024 particles
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
@@ -70,62 +60,106 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
     Vec4<T> *__restrict__ velMassOut, T *__restrict__ restDensityOut, int *__restrict__ uniqueIdOut,
     long long *__restrict__ keyOut, int capKeep, SlabRecord<T> *__restrict__ sendLeft, int capLeft,
     SlabRecord<T> *__restrict__ sendRight, int capRight, int *__restrict__ counters) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    bool keep = false, left = false, right = false, lost = false;
-    Vec4<T> p{};
-    if (i < n) {
-        bool owned = all_owned != 0;
-        if (!owned) {
-            const unsigned h = (unsigned)sortedHash[i];
-            if (h == FSA_GRID_UNDEF) {
-                owned = true;  // halo copies are always inside the grid when they arrive
-            } else {
-                const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
-                owned = gz >= R.own_lo && gz < R.own_hi;
+    constexpr int kWaves = kBlock / 64;
+    // per stream (keep, left, right): particles flagged by wave w in item round k, then their prefix
+    __shared__ int part[3][kPackItems * kWaves];
+    __shared__ int base[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * (kBlock * kPackItems);
+    Vec4<T> p[kPackItems];
+    unsigned flags[kPackItems];  // bit 0 keep, 1 left, 2 right
+    int before[kPackItems][3];   // flagged lanes below this one in its wave
+    int lost = 0;
+#pragma unroll
+    for (int k = 0; k < kPackItems; k++) {
+        const int i = first + k * kBlock + threadIdx.x;
+        flags[k] = 0;
+        p[k] = Vec4<T>{};
+        if (i < n) {
+            bool owned = all_owned != 0;
+            if (!owned) {
+                const unsigned h = (unsigned)sortedHash[i];
+                if (h == FSA_GRID_UNDEF) {
+                    owned = true;  // halo copies are always inside the grid when they arrive
+                } else {
+                    const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
+                    owned = gz >= R.own_lo && gz < R.own_hi;
+                }
+            }
+            if (owned) {
+                p[k] = posTypeIn[i];
+                bool inside = in_domain(P, p[k].x, p[k].y, p[k].z);
+                int cx = 0, cy = 0, cz = 0;
+                if (inside) {
+                    calc_grid_pos(P, p[k].x, p[k].y, p[k].z, cx, cy, cz);
+                    inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
+                }
+                if (!inside) {
+                    flags[k] = 1;  // out-of-grid particles stay with their owner
+                } else {
+                    if (cz >= R.keep_lo && cz < R.keep_hi) flags[k] |= 1;
+                    if (cz >= R.left_lo && cz < R.left_hi) flags[k] |= 2;
+                    if (cz >= R.right_lo && cz < R.right_hi) flags[k] |= 4;
+                    if (flags[k] == 0) lost++;
+                }
             }
         }
-        if (owned) {
-            p = posTypeIn[i];
-            bool inside = in_domain(P, p.x, p.y, p.z);
-            int cx = 0, cy = 0, cz = 0;
-            if (inside) {
-                calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
-                inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const unsigned long long m = __ballot((flags[k] >> c) & 1u);
+            before[k][c] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) part[c][k * kWaves + wave] = __popcll(m);
+        }
+    }
+    if (lost) atomicAdd(counters + 3, lost);
+    __syncthreads();
+    if (threadIdx.x < 3) {  // exclusive prefix over (round, wave) and one atomic for the block
+        const int c = threadIdx.x;
+        int run = 0;
+        for (int e = 0; e < kPackItems * kWaves; e++) {
+            const int v = part[c][e];
+            part[c][e] = run;
+            run += v;
+        }
+        base[c] = run ? atomicAdd(counters + c, run) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPackItems; k++) {
+        if (flags[k] == 0) continue;
+        const int i = first + k * kBlock + threadIdx.x;
+        const Vec4<T> v = velMassIn[i];
+        const T rd = restDensityIn[i];
+        const int uid = uniqueIdIn[i];
+        const long long key = keyIn[i];
+        const int e = k * kWaves + wave;
+        if (flags[k] & 1u) {
+            const int slot = base[0] + part[0][e] + before[k][0];
+            if (slot < capKeep) {
+                posTypeOut[slot] = p[k];
+                velMassOut[slot] = v;
+                restDensityOut[slot] = rd;
+                uniqueIdOut[slot] = uid;
+                keyOut[slot] = key;
             }
-            if (!inside) {
-                keep = true;  // out-of-grid particles stay with their owner
-            } else {
-                keep = cz >= R.keep_lo && cz < R.keep_hi;
-                left = cz >= R.left_lo && cz < R.left_hi;
-                right = cz >= R.right_lo && cz < R.right_hi;
-                lost = !keep && !left && !right;
+        }
+        if (flags[k] & 6u) {
+            SlabRecord<T> rec{};
+            rec.posType = p[k];
+            rec.velMass = v;
+            rec.orderKey = key;
+            rec.restDensity = rd;
+            rec.uniqueId = uid;
+            if (flags[k] & 2u) {
+                const int slot = base[1] + part[1][e] + before[k][1];
+                if (slot < capLeft) sendLeft[slot] = rec;
+            }
+            if (flags[k] & 4u) {
+                const int slot = base[2] + part[2][e] + before[k][2];
+                if (slot < capRight) sendRight[slot] = rec;
             }
         }
     }
-    const int kslot = wave_append(keep, counters + 0);
-    const int lslot = wave_append(left, counters + 1);
-    const int rslot = wave_append(right, counters + 2);
-    (void)wave_append(lost, counters + 3);
-    if (!(keep || left || right)) return;
-    const Vec4<T> v = velMassIn[i];
-    const T rd = restDensityIn[i];
-    const int uid = uniqueIdIn[i];
-    const long long key = keyIn[i];
-    if (keep && kslot < capKeep) {
-        posTypeOut[kslot] = p;
-        velMassOut[kslot] = v;
-        restDensityOut[kslot] = rd;
-        uniqueIdOut[kslot] = uid;
-        keyOut[kslot] = key;
-    }
-    SlabRecord<T> rec{};
-    rec.posType = p;
-    rec.velMass = v;
-    rec.orderKey = key;
-    rec.restDensity = rd;
-    rec.uniqueId = uid;
-    if (left && lslot < capLeft) sendLeft[lslot] = rec;
-    if (right && rslot < capRight) sendRight[rslot] = rec;
 }
 
 template <typename T>
@@ -236,7 +270,7 @@ template <typename T>
 static int pack_t(Solver *s, const DevParams<T> &P, const SlabRanges &R, void *sendLeft, int capLeft, void *sendRight,
                   int capRight) {
     const int in = s->cur, out = 1 - s->cur;
-    hipLaunchKernelGGL(slab_pack_kernel<T>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, P, s->n,
+    hipLaunchKernelGGL(slab_pack_kernel<T>, dim3((s->n + kBlock * kPackItems - 1) / (kBlock * kPackItems)), dim3(kBlock), 0, s->stream, P, s->n,
                        s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (const Vec4<T> *)s->b.posType[in],
                        (const Vec4<T> *)s->b.velMass[in], (const T *)s->b.restDensity[in], s->b.uniqueId[in],
                        s->b.orderKey[in], (Vec4<T> *)s->b.posType[out], (Vec4<T> *)s->b.velMass[out],
