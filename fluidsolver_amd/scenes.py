@@ -165,12 +165,9 @@ def reference_scene(with_boundary=True) -> dict:
     return _finish(parts, _params(REF_DOMAIN_MIN, REF_DOMAIN_MAX))
 
 
-def dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, wall_type=TYPE_BOUNDARY, spacing=0.005,
-              boundary_mode=1, walls=True) -> dict:
-    """Benchmark dam break: an nx*ny*nz fluid lattice (rest density 1000) standing in one corner of
-    a tank `tank_x_factor` times as long in x.  Tank walls and floor are one layer of wall particles
-    (TYPE_BOUNDARY, so ForceCell's penalty branch acts) placed two cells inside the grid box;
-    boundary_mode 1 adds the legacy clamp to the grid box as a safety net."""
+def dam_break_geometry(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.005, boundary_mode=1) -> dict:
+    """Boxes of the benchmark dam break (all float64; the particle generators round them to fp32):
+    grid box, fluid block corners for the half-open lattice loops, tank corners, parameters."""
     s = F32(spacing)
     sr = float(s) * 2.0
     L = np.array([nx, ny, nz], dtype=np.float64) * float(s)
@@ -186,12 +183,26 @@ def dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, wall_type=TYPE_BOUND
     f_lo = np.array([gap, gap, gap])
     eps = 0.25 * float(s)
     f_hi = f_lo + (np.array([nx, ny, nz]) - 1) * float(s) + eps
-    fluid = fluid_block(f_lo, f_hi, s, 1000.0, color=(0.2, 0.4, 1, 1))
+    # every box travels through text files too (host/config): keep what survives a decimal round trip
+    rt = lambda v: tuple(float(repr(float(x))) for x in v)
+    return {"fluid_lo": rt(f_lo), "fluid_hi": rt(f_hi), "tank_lo": (0.0, 0.0, 0.0), "tank_hi": rt(tank),
+            "params": _params(rt(vmin), rt(vmax), boundary_mode=boundary_mode, viscosity=WCSPH_VISCOSITY)}
+
+
+def dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, wall_type=TYPE_BOUNDARY, spacing=0.005,
+              boundary_mode=1, walls=True) -> dict:
+    """Benchmark dam break: an nx*ny*nz fluid lattice (rest density 1000) standing in one corner of
+    a tank `tank_x_factor` times as long in x.  Tank walls and floor are one layer of wall particles
+    (TYPE_BOUNDARY, so ForceCell's penalty branch acts) placed two cells inside the grid box;
+    boundary_mode 1 adds the legacy clamp to the grid box as a safety net."""
+    s = F32(spacing)
+    g = dam_break_geometry(nx, ny, nz, tank_x_factor, head_room, spacing, boundary_mode)
+    fluid = fluid_block(g["fluid_lo"], g["fluid_hi"], s, 1000.0, color=(0.2, 0.4, 1, 1))
     parts = [fluid]
     if walls:
-        parts.append(open_box((0.0, 0.0, 0.0), tuple(tank - 0.0), s, group=1, ptype=wall_type,
+        parts.append(open_box(g["tank_lo"], g["tank_hi"], s, group=1, ptype=wall_type,
                               mass=rigid_mass(s, 1000.0), rest_density=1000.0))
-    sc = _finish(parts, _params(vmin, vmax, boundary_mode=boundary_mode, viscosity=WCSPH_VISCOSITY))
+    sc = _finish(parts, g["params"])
     sc["n_fluid"] = len(fluid["pos"])
     return sc
 

@@ -1,0 +1,164 @@
+"""C++ host layer (fluidsolver_amd/host): the plugin classes main.cpp drives, the config readers, the
+headless GUI stand-in.
+
+CPU part: the scene the C++ code builds from host/config equals, bit for bit, the scene of
+fluidsolver_amd.scenes that the oracle parity tests use; the reference's own main.cpp compiles and links
+against these headers unchanged (only where the reference tree is present).
+GPU part: the built program runs the scene through the C ABI and ends in the same state as the Python
+binding driving the same library.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fluidsolver_amd import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "fluidsolver_amd", "host")
+REF = "/root/reference/particle_solver"
+
+
+def have_bins():
+    return all(os.path.exists(os.path.join(HOST, "bin", b)) for b in ("particle_solver", "scene_dump"))
+
+
+def env_for(scene_id):
+    e = dict(os.environ)
+    e.update(FSA_CONFIG_DIR=os.path.join(HOST, "config"), FSA_SCENE_ID=str(scene_id))
+    return e
+
+
+def read_scene_dump(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(raw[:4].view(np.int32)[0])
+    res = raw[4:16].view(np.int32).tolist()
+    consts = raw[16:40].view(np.float64).tolist()
+    o = 40
+    out = {"n": n, "gridres": res, "dx": consts[0], "kernel_cubic": consts[1], "kspikydiff": consts[2]}
+    for name, dt, w in (("pos", np.float32, 3), ("color", np.float32, 4), ("normal", np.float32, 3),
+                        ("type", np.int32, 1), ("group", np.int32, 1), ("mass", np.float32, 1),
+                        ("restDensity", np.float32, 1)):
+        nb = n * w * 4
+        a = raw[o:o + nb].view(dt)
+        out[name] = a.reshape(n, w) if w > 1 else a
+        o += nb
+    assert o == raw.size
+    return out
+
+
+@pytest.mark.skipif(not have_bins(), reason="host layer not built (make -C fluidsolver_amd/host)")
+@pytest.mark.parametrize("scene_id,build", [(2, lambda: scenes.reference_scene()),
+                                            (20, lambda: scenes.dam_break(64, 32, 64))])
+def test_cpp_scene_setup_equals_python_scene(tmp_path, scene_id, build):
+    out = tmp_path / "scene.bin"
+    subprocess.check_call([os.path.join(HOST, "bin", "scene_dump"), str(out)], env=env_for(scene_id),
+                          stdout=subprocess.DEVNULL)
+    got = read_scene_dump(out)
+    sc = build()
+    assert got["n"] == len(sc["pos"])
+    for k in ("pos", "normal", "type", "group", "mass", "restDensity"):
+        assert np.ascontiguousarray(got[k]).tobytes() == np.ascontiguousarray(sc[k]).tobytes(), k
+    if scene_id == 2:
+        assert np.array_equal(got["color"], sc["color"])
+    from fluidsolver_amd import capi
+    p = capi.make_params(capi.PRECISION_F32, **sc["params"])
+    assert got["gridres"] == list(p.gridres)
+    assert (got["dx"], got["kernel_cubic"], got["kspikydiff"]) == (p.dx, p.kernel_cubic, p.kspikydiff)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_main_compiles_against_host_headers(tmp_path):
+    """main.cpp of the reference, where it lies, with its three includes resolved to this layer."""
+    subprocess.check_call(["make", "-C", HOST, "refmain", f"REF={REF}", f"OUT={tmp_path}"],
+                          stdout=subprocess.DEVNULL)
+    exe = tmp_path / "particle_solver_refmain"
+    assert exe.exists()
+    syms = subprocess.check_output(["nm", "-C", "--undefined-only", str(exe)], text=True)
+    assert "fsa_step" in syms or "fsa_compute_force" in syms  # it calls into the C ABI, nothing else does the work
+
+
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_xml_reader_conventions(tmp_path):
+    """missing tags read as 0, comments are skipped, several top-level elements are fine"""
+    cfg = tmp_path / "config"
+    cfg.mkdir()
+    (cfg / "sph_scene.xml").write_text("""<?xml version="1.0"?>
+<!-- a comment with <tags> inside -->
+<Fluid><Gravity> 0, -10, 0 </Gravity><VolMin> -0.1,-0.1,-0.1 </VolMin><VolMax> 0.1, 0.1, 0.1 </VolMax>
+<SceneId> 7 </SceneId></Fluid>
+<MultiScene id="3"><PSpacing> 0.5 </PSpacing></MultiScene>
+<MultiScene id="7"><TypeNum> 2 </TypeNum><DT> 0.001 </DT><PSpacing> 0.01 </PSpacing><SmoothRatio> 2 </SmoothRatio>
+ <DensityArray> 800,1200 </DensityArray><ViscosityArray> 1,1 </ViscosityArray>
+ <!--Vol><VolMin> 9,9,9 </VolMin></Vol-->
+ <Vol><VolMin> 0,0,0 </VolMin><VolMax> 0.0301, 0.0201, 0.0101 </VolMax><VolFrac> 0.25, 0.75 </VolFrac></Vol>
+</MultiScene>""")
+    (cfg / "big box.xml").write_text("<Boundary><Cube><xmin>0,0,0</xmin><xmax>0.01,0,0</xmax>"
+                                     "<spacing>0.01</spacing><normal>0,1,0</normal><id>5</id></Cube></Boundary>")
+    e = dict(os.environ, FSA_CONFIG_DIR=str(cfg))
+    e.pop("FSA_SCENE_ID", None)
+    out = tmp_path / "s.bin"
+    subprocess.check_call([os.path.join(HOST, "bin", "scene_dump"), str(out)], env=e, stdout=subprocess.DEVNULL)
+    got = read_scene_dump(out)
+    nx = len(scenes.lattice_axis(0, 0.0301, 0.01))
+    ny = len(scenes.lattice_axis(0, 0.0201, 0.01))
+    nz = len(scenes.lattice_axis(0, 0.0101, 0.01))
+    n_fluid = nx * ny * nz
+    assert got["n"] == n_fluid + 2
+    assert got["gridres"] == [10, 10, 10]
+    f32 = np.float32
+    dens = f32(f32(800) * f32(0.25)) + f32(f32(1200) * f32(0.75))
+    assert np.all(got["restDensity"][:n_fluid] == dens)
+    assert np.all(got["type"][:n_fluid] == 0) and np.all(got["type"][n_fluid:] == 4)
+    assert np.all(got["group"][n_fluid:] == 5)
+    assert np.all(got["mass"][n_fluid:] == 0)  # RestDensity tag is missing: reads as 0
+
+
+def read_final(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = int(raw[:4].view(np.int32)[0])
+    pos = raw[4:4 + n * 12].view(np.float32).reshape(n, 3)
+    col = raw[4 + n * 12:4 + n * 28].view(np.float32).reshape(n, 4)
+    return pos, col
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+@pytest.mark.parametrize("scene_id", [2, 20])
+def test_headless_program_matches_python_binding(tmp_path, scene_id):
+    from fluidsolver_amd import capi
+    frames = 12
+    final = tmp_path / "final.bin"
+    dump_dir = tmp_path / "dump"
+    dump_dir.mkdir()
+    e = env_for(scene_id)
+    e["FSA_DUMP_DIR"] = str(dump_dir)
+    subprocess.check_call([os.path.join(HOST, "bin", "particle_solver"), "--frames", str(frames), "--save-final",
+                           str(final), "--keys", "b"], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    pos, col = read_final(final)
+
+    sc = scenes.reference_scene() if scene_id == 2 else scenes.dam_break(64, 32, 64)
+    if scene_id == 20:
+        sc = dict(sc)
+        sc["color"] = np.tile(np.asarray((1, 0, 0, 1), np.float32), (len(sc["pos"]), 1))
+        sc["color"][sc["type"] != 0] = (1, 1, 1, 0.5)
+    p = capi.make_params(capi.PRECISION_F32, **sc["params"])
+    s = capi.Solver(p, len(sc["pos"]))
+    s.upload(sc)
+    s.sort_particles()
+    s.rigid_particle_volume()
+    s.step(frames)
+    want_pos, want_col = s.readback_pos_color()
+    assert pos.tobytes() == want_pos.tobytes()
+    assert col.tobytes() == want_col.tobytes()
+
+    # the text checkpoint written by key 'b' holds the same state (6 decimals)
+    lines = (dump_dir / f"{frames:03d}.txt").read_text().splitlines()
+    assert int(lines[0]) == len(pos)
+    rows = np.array([l.split() for l in lines[1:]], dtype=np.float64)
+    assert np.abs(rows[:, 0:3] - want_pos).max() < 1e-6
+    assert np.abs(rows[:, 3:6] - s.get("vel")).max() < 1e-6
+    assert np.array_equal(rows[:, 6].astype(int), s.get("type"))
+    assert np.array_equal(rows[:, 9].astype(int), s.get("uniqueId"))
+    s.close()
