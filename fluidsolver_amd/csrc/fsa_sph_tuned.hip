@@ -209,6 +209,18 @@ __device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P
         }
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and every XCD has
+// its own L2.  Blocks of consecutive sorted particles share most of their neighbour rows, so runs of
+// 64 consecutive blocks go to one XCD instead of every eighth block (measured: 5 % on the force pass;
+// one contiguous eighth of the range per XCD is slower, the eighths differ too much in cost).
+constexpr int kXcds = 8;
+constexpr int kXcdRunLog = 6;
+constexpr int kXcdUnit = kXcds << kXcdRunLog;  // the launchers round the grid up to a multiple of this
+__device__ __forceinline__ int xcd_block() {
+    const int x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+    return ((k >> kXcdRunLog) * kXcds + x) * (1 << kXcdRunLog) + (k & ((1 << kXcdRunLog) - 1));
+}
+
 static int g_ablate = 0;        // timing experiments only (debug_time_pass)
 static void *g_out0 = nullptr;  // when set, results go to these scratch arrays instead
 static void *g_out1 = nullptr;
@@ -230,7 +242,8 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     __shared__ RowShared<BS, ROWCAP> sh;
     __shared__ float queue[Q * BS];
     const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * BS;
+    const int b0 = xcd_block() * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     const bool active = index < n;
@@ -381,7 +394,8 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     __shared__ RowShared<BS, ROWCAP> sh;
     __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
     const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * BS;
+    const int b0 = xcd_block() * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
 
@@ -583,10 +597,10 @@ constexpr int kQueueF = 32;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    const int ablate = g_ablate;
     ScopedTimer t(s, g_out0 ? "density_dbg" : "density");
     const int c = s->cur;
-    const int nb = (s->n + kTunedBS - 1) / kTunedBS;
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + kXcdUnit - 1) / kXcdUnit * kXcdUnit;
+    const int ablate = g_ablate;
     float *out0 = (float *)(g_out0 ? g_out0 : s->b.density), *out1 = (float *)(g_out1 ? g_out1 : s->b.pressure);
     if (s->variant == 2)
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, true>), dim3(nb), dim3(kTunedBS), 0,
@@ -617,7 +631,7 @@ int launch_force_tuned(Solver *s) {
                                (const float *)s->b.pressure, (float2 *)s->b.pd);
     }
     ScopedTimer t(s, g_out0 ? "force_dbg" : "force");
-    const int nb = (s->n + kTunedBS - 1) / kTunedBS;
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + kXcdUnit - 1) / kXcdUnit * kXcdUnit;
     const int ablate = g_ablate;
     Vec3<float> *out = (Vec3<float> *)(g_out0 ? g_out0 : s->b.force);
     if (fast)
