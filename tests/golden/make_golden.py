@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Generates the fixtures in this directory from the CPU oracle (oracle/sph_oracle.c).
+
+    python tests/golden/make_golden.py
+
+The reference ships no golden vectors for this path and cannot be built here, so these files pin the
+ORACLE (and, through the GPU tests, the HIP path) against silent change; they are not outputs of the
+reference.  One file per precision: the inputs of a small noisy dam break with wall particles and the
+outputs of every stage of one step, plus the positions after five whole steps.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from fluidsolver_amd import scenes  # noqa: E402
+from oracle.orc import Oracle  # noqa: E402
+from util import oracle_pair  # noqa: E402
+
+
+def golden_scene():
+    sc = scenes.dam_break(14, 12, 10, tank_x_factor=2.0)
+    return scenes.jittered(sc, seed=4242, pos_jitter=0.2, vel_scale=1.0)
+
+
+def generate(precision):
+    orc = Oracle(precision)
+    orc.set_threads(1)
+    sc = golden_scene()
+    p, st = oracle_pair(orc, sc)
+    out = {"params_json": np.frombuffer(json.dumps(sc["params"]).encode(), dtype=np.uint8)}
+    for k in ("pos", "vel", "type", "mass", "restDensity", "color", "normal", "group", "uniqueId"):
+        out["in_" + k] = np.asarray(sc[k])
+    st.calc_hash(p)
+    out["hash_unsorted"] = st["particleHash"].copy()
+    st.sort_particle()
+    out["particleHash"] = st["particleHash"].copy()
+    out["particleIndex"] = st["particleIndex"].copy()
+    st.reorder(p)
+    st.copy_sorted_to_primary()
+    out["gridCellStart"] = st["gridCellStart"].copy()
+    ge = st["gridCellEnd"].copy()
+    ge[st["gridCellStart"] == -1] = 0  # undefined for empty cells
+    out["gridCellEnd"] = ge
+    out["sorted_uniqueId"] = st["uniqueId"].copy()
+    out["indexTable"] = st["indexTable"].copy()
+    st.compute_pressure(p)
+    out["density"] = st["density"].copy()
+    out["pressure"] = st["pressure"].copy()
+    st.compute_force(p)
+    out["force"] = st["force"].copy()
+    st.advect(p)
+    out["pos_after"] = st["pos"].copy()
+    out["vel_after"] = st["vel"].copy()
+    out["v_star_after"] = st["v_star"].copy()
+    st.solve_sph(p, 4)
+    order = np.argsort(st["uniqueId"])
+    out["pos_step5_by_id"] = st["pos"][order].copy()
+    st.close()
+    path = os.path.join(HERE, f"small_dam_{precision}.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    generate("f32")
+    generate("f64")
