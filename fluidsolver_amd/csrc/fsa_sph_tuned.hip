@@ -5,11 +5,13 @@
 // ONE contiguous cell range [hlo + off - 1, hhi + off + 1], hence one contiguous particle range
 // ("row").  The kernel walks the 9 rows in the reference's order (z outer, y inner):
 //
-//   * the row's {x, y, z, type} are copied into a small LDS buffer with coalesced 16-byte loads;
-//     two buffers alternate, the global loads of row r + 1 (and of the lane's cell range in it)
-//     are issued before row r is examined and land after it, so their latency is hidden;
-//   * phase 1 (cull): every lane walks its own index range of the row four candidates at a time
-//     (four ds_read_b128 in flight, straight-line code, no divergent branches) and appends those
+//   * the row's {x, y, z, type} are copied into a small LDS buffer with coalesced 16-byte loads and
+//     stored there as separate x / y / z / type arrays; two buffers alternate, the global loads of
+//     row r + 1 (and of the lane's cell range in it) are issued before row r is examined and land
+//     after it, so their latency is hidden;
+//   * phase 1 (cull): every lane walks its own index range of the row in aligned groups of four
+//     candidates (one ds_read_b128 per coordinate gives four candidates, straight-line code, no
+//     divergent branches; the first and the last group of a range are masked) and appends those
 //     that pass the distance test to its private queue in LDS (queue[slot][lane]: conflict-free).
 //     The append is branch-free: all four candidates are stored, each at the slot counted up by
 //     the hits before it, so a miss is simply overwritten by the next store;
@@ -40,18 +42,24 @@ constexpr int kChunk = 4;  // candidates fetched per lane and loop trip
 constexpr int kDrainBatch = 2;  // force drain: neighbours per batch (two batches in flight)
 constexpr float kFar = 3.0e18f;
 
-template <int BS, int ROWCAP> struct RowShared {
-    float4 row[2][ROWCAP + kChunk];  // + far-away padding read by the last chunk of a lane
-    int rowStartG[9];                // first particle (global index) of each row
+// Row tile in LDS, coordinates apart so that one 16-byte read yields four candidates.  The group
+// after the last full one (index ROWCAP / 4) only ever holds far-away padding: lanes that have nothing
+// left to do read it.
+template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
+    static constexpr int kGroups = (ROWCAP + kChunk) / kChunk;
+    static constexpr int kPad = ROWCAP / kChunk;
+    float4 x[2][kGroups], y[2][kGroups], z[2][kGroups];
+    int4 t[WITH_TYPE ? 2 : 1][WITH_TYPE ? kGroups : 1];
+    int rowStartG[9];  // first particle (global index) of each row
     int rowLen[9];
     int staged;
 };
 
-// Block-uniform set-up.  Returns false when this block must take the generic path.
-template <int BS, int ROWCAP>
+// Block-uniform set-up.  Returns false when this block must take the per-particle path.
+template <int ROWCAP, typename Shared>
 __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, int nb,
                                            const int *__restrict__ cellStart,
-                                           const int *__restrict__ sortedHash, RowShared<BS, ROWCAP> &sh) {
+                                           const int *__restrict__ sortedHash, Shared &sh) {
     const int tid = threadIdx.x;
     const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
     const int C = P.num_cells;
@@ -85,9 +93,9 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // Row r of the tile: every thread fetches its (at most two) entries into registers ...
 // FLUID_ONLY: particles of any other type are moved far away, so that the cull needs no type test.
-template <int BS, int ROWCAP, bool FLUID_ONLY>
-__device__ __forceinline__ void row_fetch(const RowShared<BS, ROWCAP> &sh, int r,
-                                          const float4 *__restrict__ posType, float4 &e0, float4 &e1) {
+template <int BS, int ROWCAP, bool FLUID_ONLY, typename Shared>
+__device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 *__restrict__ posType, float4 &e0,
+                                          float4 &e1) {
     static_assert(ROWCAP + kChunk <= 2 * BS, "two entries per thread must cover a row");
     const int tid = threadIdx.x;
     const int s = sh.rowStartG[r], len = sh.rowLen[r];
@@ -100,18 +108,28 @@ __device__ __forceinline__ void row_fetch(const RowShared<BS, ROWCAP> &sh, int r
     if (tid + BS >= len || (FLUID_ONLY && unpack_int(e1.w) != FSA_TYPE_FLUID)) e1 = far;
 }
 // ... and stores them later, after the previous row has been examined.
-template <int BS, int ROWCAP>
-__device__ __forceinline__ void row_store(RowShared<BS, ROWCAP> &sh, int buf, const float4 &e0, const float4 &e1) {
+template <int BS, int ROWCAP, bool WITH_TYPE, typename Shared>
+__device__ __forceinline__ void row_store(Shared &sh, int buf, const float4 &e0, const float4 &e1) {
     const int tid = threadIdx.x;
-    sh.row[buf][tid] = e0;
-    if (tid + BS < ROWCAP + kChunk) sh.row[buf][tid + BS] = e1;
+    float *const x = reinterpret_cast<float *>(sh.x[buf]);
+    float *const y = reinterpret_cast<float *>(sh.y[buf]);
+    float *const z = reinterpret_cast<float *>(sh.z[buf]);
+    x[tid] = e0.x;
+    y[tid] = e0.y;
+    z[tid] = e0.z;
+    if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[tid] = unpack_int(e0.w);
+    if (tid + BS < ROWCAP + kChunk) {
+        x[tid + BS] = e1.x;
+        y[tid + BS] = e1.y;
+        z[tid + BS] = e1.z;
+        if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[tid + BS] = unpack_int(e1.w);
+    }
 }
 
 // The lane's index range in row r, relative to the row's first particle (two loads of the cell table).
-template <int BS, int ROWCAP>
-__device__ __forceinline__ void lane_range(const DevParams<float> &P, const RowShared<BS, ROWCAP> &sh,
-                                           const RowWalk<float> &walk, bool active, int r,
-                                           const int *__restrict__ cellStart, int &lj, int &le) {
+template <typename Shared>
+__device__ __forceinline__ void lane_range(const DevParams<float> &P, const Shared &sh, const RowWalk<float> &walk,
+                                           bool active, int r, const int *__restrict__ cellStart, int &lj, int &le) {
     lj = 0;
     le = 0;
     if (active) {
@@ -121,6 +139,18 @@ __device__ __forceinline__ void lane_range(const DevParams<float> &P, const RowS
             lj = cellStart[c] - s;
             le = cellStart[c + (walk.xhi - walk.xlo) + 1] - s;
         }
+    }
+}
+
+// Squared distances of the four candidates of group g to the point (px, py, pz).
+template <bool FAST>
+__device__ __forceinline__ void group_d2(const float4 &X, const float4 &Y, const float4 &Z, float px, float py,
+                                         float pz, float (&d2)[kChunk]) {
+    const float xs[kChunk] = {X.x, X.y, X.z, X.w}, ys[kChunk] = {Y.x, Y.y, Y.z, Y.w}, zs[kChunk] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+    for (int u = 0; u < kChunk; u++) {
+        const float xx = px - xs[u], xy = py - ys[u], xz = pz - zs[u];
+        d2[u] = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx)) : xx * xx + xy * xy + xz * xz;
     }
 }
 
@@ -214,11 +244,17 @@ __device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P
 // 64 consecutive blocks go to one XCD instead of every eighth block (measured: 5 % on the force pass;
 // one contiguous eighth of the range per XCD is slower, the eighths differ too much in cost).
 constexpr int kXcds = 8;
-constexpr int kXcdRunLog = 6;
-constexpr int kXcdUnit = kXcds << kXcdRunLog;  // the launchers round the grid up to a multiple of this
-__device__ __forceinline__ int xcd_block() {
+static int xcd_run_log() {  // FSA_XCD_RUN_LOG overrides the run length (log2) for experiments
+    static const int v = [] {
+        const char *e = getenv("FSA_XCD_RUN_LOG");
+        const int x = e ? atoi(e) : 6;
+        return x < 0 ? 0 : (x > 12 ? 12 : x);
+    }();
+    return v;
+}
+__device__ __forceinline__ int xcd_block(int run_log) {
     const int x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
-    return ((k >> kXcdRunLog) * kXcds + x) * (1 << kXcdRunLog) + (k & ((1 << kXcdRunLog) - 1));
+    return ((k >> run_log) * kXcds + x) * (1 << run_log) + (k & ((1 << run_log) - 1));
 }
 
 static int g_ablate = 0;        // timing experiments only (debug_time_pass)
@@ -239,15 +275,16 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
                                                            const int *__restrict__ sortedHash,
                                                            float *__restrict__ density,
                                                            float *__restrict__ pressure, int ablate) {
-    __shared__ RowShared<BS, ROWCAP> sh;
+    using Shared = RowShared<BS, ROWCAP, false>;
+    __shared__ Shared sh;
     __shared__ float queue[Q * BS];
     const int tid = threadIdx.x;
-    const int b0 = xcd_block() * BS;
+    const int b0 = xcd_block(ablate >> 8) * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     const bool active = index < n;
-    const bool staged = setup_rows<BS, ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -291,7 +328,7 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
         int lj, le, nlj = 0, nle = 0;
         row_fetch<BS, ROWCAP, true>(sh, 0, posType, e0, e1);
         lane_range(P, sh, walk, active, 0, cellStart, lj, le);
-        row_store(sh, 0, e0, e1);
+        row_store<BS, ROWCAP, false>(sh, 0, e0, e1);
         __syncthreads();
         for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
             const int buf = r & 1;
@@ -299,54 +336,39 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
                 row_fetch<BS, ROWCAP, true>(sh, r + 1, posType, e0, e1);
                 lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
             }
-            const float4 *__restrict__ row = sh.row[buf];
             if (ablate & 4) lj = le;
-            // full chunks: all four candidates belong to the lane's range
-            while (wave_any(lj + kChunk <= le)) {
-                const bool go = lj + kChunk <= le;
-                const int base = go ? lj : ROWCAP;  // lanes with less than a chunk left read far-away padding
-                float4 c4[kChunk];
-#pragma unroll
-                for (int u = 0; u < kChunk; u++) c4[u] = row[base + u];
+            // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
+            auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
                 float d2[kChunk];
+                group_d2<FAST>(sh.x[buf][g], sh.y[buf][g], sh.z[buf][g], pi.x, pi.y, pi.z, d2);
+                if (ablate & 2) return;
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    const float xx = pi.x - c4[u].x, xy = pi.y - c4[u].y, xz = pi.z - c4[u].z;
-                    d2[u] = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx))
-                                 : xx * xx + xy * xy + xz * xz;
+                    q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
+                    cnt += (d2[u] < sr2 && (!MASKED || (u >= lo && u < hi))) ? 1 : 0;
                 }
-                if (!(ablate & 2)) {
-#pragma unroll
-                    for (int u = 0; u < kChunk; u++) {
-                        q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
-                        cnt += d2[u] < sr2 ? 1 : 0;
-                    }
-                }
-                lj += go ? kChunk : 0;
+            };
+            const bool has = lj < le;
+            int base = lj & ~(kChunk - 1);
+            if (wave_any(has)) {  // first group of the range: candidates below lj belong to other cells
+                cull_group(has ? base / kChunk : Shared::kPad, lj - base, le - base, std::true_type());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
-            // tail: the last one to three candidates of the range (what follows them in the row belongs
-            // to other cells and may well be close, so it is masked out)
-            if (wave_any(lj < le)) {
-                const int rem = le - lj;  // 0..3
-                const int base = rem > 0 ? lj : ROWCAP;
-                float4 c4[kChunk - 1];
-#pragma unroll
-                for (int u = 0; u < kChunk - 1; u++) c4[u] = row[base + u];
-#pragma unroll
-                for (int u = 0; u < kChunk - 1; u++) {
-                    const float xx = pi.x - c4[u].x, xy = pi.y - c4[u].y, xz = pi.z - c4[u].z;
-                    const float d2 = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx))
-                                          : xx * xx + xy * xy + xz * xz;
-                    if (!(ablate & 2)) {
-                        q[cnt * BS] = d2;
-                        cnt += (d2 < sr2 && u < rem) ? 1 : 0;
-                    }
-                }
+            base = has ? base + kChunk : le;
+            while (wave_any(base + kChunk <= le)) {  // whole groups
+                const bool go = base + kChunk <= le;
+                cull_group(go ? base / kChunk : Shared::kPad, 0, kChunk, std::false_type());
+                base += go ? kChunk : 0;
+                if (wave_any(cnt > Q - kChunk)) drain();
+            }
+            if (wave_any(base < le)) {  // last group: what follows the range in it belongs to other cells
+                const int rem = le - base;
+                cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
             if (r + 1 < 9) {
-                row_store(sh, buf ^ 1, e0, e1);
+                row_store<BS, ROWCAP, false>(sh, buf ^ 1, e0, e1);
                 lj = nlj;
                 le = nle;
                 __syncthreads();  // row r + 1 visible; everyone is done with row r - 1's buffer
@@ -391,10 +413,11 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                                                          const int *__restrict__ cellStart,
                                                          const int *__restrict__ sortedHash,
                                                          Vec3<float> *__restrict__ force, int ablate) {
-    __shared__ RowShared<BS, ROWCAP> sh;
+    using Shared = RowShared<BS, ROWCAP, true>;
+    __shared__ Shared sh;
     __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
     const int tid = threadIdx.x;
-    const int b0 = xcd_block() * BS;
+    const int b0 = xcd_block(ablate >> 8) * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     // a block without fluid particles (wall layers) has nothing to do
     if (!__syncthreads_or(active ? 1 : 0)) return;
-    const bool staged = setup_rows<BS, ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
     if (active) {
         S.v = velMass[index];
         S.pterm = pd[index].x;
@@ -506,7 +529,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
         int lj, le, nlj = 0, nle = 0;
         row_fetch<BS, ROWCAP, false>(sh, 0, posType, e0, e1);
         lane_range(P, sh, walk, active, 0, cellStart, lj, le);
-        row_store(sh, 0, e0, e1);
+        row_store<BS, ROWCAP, true>(sh, 0, e0, e1);
         __syncthreads();
         for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
             const int buf = r & 1;
@@ -514,58 +537,59 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                 row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e0, e1);
                 lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
             }
-            const float4 *__restrict__ row = sh.row[buf];
             const int tag = r << 9;
             if (ablate & 4) lj = le;
-            // One chunk of NU candidates starting at `base`; `rem` = how many of them belong to the lane.
-            auto cull_chunk = [&](int base, int rem, auto nu_tag) {
-                constexpr int NU = decltype(nu_tag)::value;
-                float4 c4[NU];
-#pragma unroll
-                for (int u = 0; u < NU; u++) c4[u] = row[base + u];
-                float d2[NU];
-                int types = 0;
-#pragma unroll
-                for (int u = 0; u < NU; u++) {
-                    const float xx = S.p.x - c4[u].x, xy = S.p.y - c4[u].y, xz = S.p.z - c4[u].z;
-                    d2[u] = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                    types |= unpack_int(c4[u].w);
-                }
-                const int etag = tag | base;
-                if (ablate & 2) {
-                } else if (!wave_any(types != 0)) {
+            // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
+            auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                float d2[kChunk];
+                // the queue only has to hold a superset of the neighbours: the fused sum decides here,
+                // the evaluation repeats the test in its own arithmetic
+                group_d2<true>(sh.x[buf][g], sh.y[buf][g], sh.z[buf][g], S.p.x, S.p.y, S.p.z, d2);
+                const int4 T = sh.t[buf][g];
+                const int tj[kChunk] = {T.x, T.y, T.z, T.w};
+                const int etag = tag | (g * kChunk);
+                if (ablate & 2) return;
+                if (!wave_any((T.x | T.y | T.z | T.w) != 0)) {
                     // only fluid candidates (the common case): branch-free append
 #pragma unroll
-                    for (int u = 0; u < NU; u++) {
+                    for (int u = 0; u < kChunk; u++) {
                         q[cnt * BS] = (unsigned short)(etag + u);  // a miss is overwritten by the next store
-                        cnt += (d2[u] < sr2c && u < rem) ? 1 : 0;
+                        cnt += (d2[u] < sr2c && (!MASKED || (u >= lo && u < hi))) ? 1 : 0;
                     }
                 } else {
                     // wall or other particles among the candidates: boundary neighbours always count,
                     // fluid ones inside the support, everything else never
 #pragma unroll
-                    for (int u = 0; u < NU; u++) {
-                        const int tj = unpack_int(c4[u].w);
-                        if (u < rem && ((tj == FSA_TYPE_FLUID && d2[u] < sr2c) || tj == FSA_TYPE_BOUNDARY)) {
+                    for (int u = 0; u < kChunk; u++) {
+                        const bool mine = !MASKED || (u >= lo && u < hi);
+                        if (mine && ((tj[u] == FSA_TYPE_FLUID && d2[u] < sr2c) || tj[u] == FSA_TYPE_BOUNDARY)) {
                             q[cnt * BS] = (unsigned short)(etag + u);
                             cnt++;
                         }
                     }
                 }
             };
-            while (wave_any(lj + kChunk <= le)) {  // full chunks
-                const bool go = lj + kChunk <= le;
-                cull_chunk(go ? lj : ROWCAP, go ? kChunk : 0, std::integral_constant<int, kChunk>());
-                lj += go ? kChunk : 0;
+            const bool has = lj < le;
+            int base = lj & ~(kChunk - 1);
+            if (wave_any(has)) {  // first group of the range
+                cull_group(has ? base / kChunk : Shared::kPad, lj - base, le - base, std::true_type());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
-            if (wave_any(lj < le)) {  // tail: the last one to three candidates of the range
-                const int rem = le - lj;
-                cull_chunk(rem > 0 ? lj : ROWCAP, rem, std::integral_constant<int, kChunk - 1>());
+            base = has ? base + kChunk : le;
+            while (wave_any(base + kChunk <= le)) {  // whole groups
+                const bool go = base + kChunk <= le;
+                cull_group(go ? base / kChunk : Shared::kPad, 0, kChunk, std::false_type());
+                base += go ? kChunk : 0;
+                if (wave_any(cnt > Q - kChunk)) drain();
+            }
+            if (wave_any(base < le)) {  // last group of the range
+                const int rem = le - base;
+                cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
             if (r + 1 < 9) {
-                row_store(sh, buf ^ 1, e0, e1);
+                row_store<BS, ROWCAP, true>(sh, buf ^ 1, e0, e1);
                 lj = nlj;
                 le = nle;
                 __syncthreads();
@@ -592,15 +616,16 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
 // ------------------------------------------------------------------------------------------------
 constexpr int kTunedBS = 256;
 constexpr int kRowCap = 384;  // typical row: 34 cells x 8 particles = 272
-constexpr int kQueueD = 24;   // density: 4-byte slots
-constexpr int kQueueF = 32;   // force: 2-byte slots
+constexpr int kQueueD = 12;   // density: 4-byte slots
+constexpr int kQueueF = 48;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
     ScopedTimer t(s, g_out0 ? "density_dbg" : "density");
     const int c = s->cur;
-    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + kXcdUnit - 1) / kXcdUnit * kXcdUnit;
-    const int ablate = g_ablate;
+    const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    const int ablate = (g_ablate & 255) | (xcd_run_log() << 8);
     float *out0 = (float *)(g_out0 ? g_out0 : s->b.density), *out1 = (float *)(g_out1 ? g_out1 : s->b.pressure);
     if (s->variant == 2)
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, true>), dim3(nb), dim3(kTunedBS), 0,
@@ -631,8 +656,9 @@ int launch_force_tuned(Solver *s) {
                                (const float *)s->b.pressure, (float2 *)s->b.pd);
     }
     ScopedTimer t(s, g_out0 ? "force_dbg" : "force");
-    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + kXcdUnit - 1) / kXcdUnit * kXcdUnit;
-    const int ablate = g_ablate;
+    const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    const int ablate = (g_ablate & 255) | (xcd_run_log() << 8);
     Vec3<float> *out = (Vec3<float> *)(g_out0 ? g_out0 : s->b.force);
     if (fast)
         hipLaunchKernelGGL((force_tuned_kernel<kTunedBS, kRowCap, kQueueF, true>), dim3(nb), dim3(kTunedBS), 0,
