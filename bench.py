@@ -133,7 +133,7 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("FSA_FORCE_SLABS") == "1":  # (env: slab path on one GPU)
         from fluidsolver_amd import slabs
         res = slabs.bench_distributed(args, build_scene)
     else:
@@ -148,8 +148,10 @@ def main():
               default=None)
     roof = None
     if dom:
-        units = res["n_fluid"] if dom == "force" else res["n"]
-        units = units / max(1, args.gpus)
+        if "local_n" in res:  # slab run: the kernel timings are rank 0's, over the particles it holds
+            units = res["local_n_fluid"] if dom == "force" else res["local_n"]
+        else:
+            units = res["n_fluid"] if dom == "force" else res["n"]
         byts = ALGO_BYTES[dom] * units
         avg_s = kernels[dom]["avg_ms"] * 1e-3
         achieved = byts / avg_s / 1e9 if avg_s > 0 else 0.0

@@ -29,7 +29,8 @@ EXPORTS = (
     "fsa_sort_particles", "fsa_compute_pressure", "fsa_compute_force", "fsa_advect",
     "fsa_rigid_particle_volume", "fsa_step", "fsa_readback_pos_color", "fsa_get_buffer", "fsa_set_buffer",
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant",
-    "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_set_scene_has_rigid",
+    "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned",
+    "fsa_set_scene_has_rigid",
 )
 
 
@@ -120,6 +121,7 @@ def load() -> C.CDLL:
         "fsa_slab_pack": [H] + [C.POINTER(C.c_int)] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                            C.POINTER(C.c_int)],
         "fsa_slab_unpack": [H, C.c_void_p, C.c_int],
+        "fsa_slab_set_owned": [H, C.POINTER(C.c_int)],
         "fsa_set_scene_has_rigid": [H, C.c_int],
     }
     for name, args in protos.items():
@@ -301,6 +303,9 @@ class Solver:
 
     def slab_unpack(self, records_ptr, count):
         check(self.lib.fsa_slab_unpack(self._h, C.c_void_p(records_ptr), int(count)))
+
+    def slab_set_owned(self, own):
+        check(self.lib.fsa_slab_set_owned(self._h, (C.c_int * 2)(*own)))
 
     def set_scene_has_rigid(self, flag: bool):
         check(self.lib.fsa_set_scene_has_rigid(self._h, 1 if flag else 0))

@@ -77,6 +77,8 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.z0 = h.slab_nz > 0 ? h.slab_z0 : 0;
     d.nz = h.slab_nz > 0 ? h.slab_nz : h.gridres[2];
     d.num_cells = h.gridres[0] * h.gridres[1] * d.nz;
+    d.own_lo = -(1 << 30);
+    d.own_hi = 1 << 30;
 }
 
 static int check_params(const fsa_params *p) {
@@ -310,9 +312,12 @@ int fsa_copy_param_to_device(fsa_solver *hs, const fsa_params *p) {
     if (nf.num_cells != s->num_cells || nf.gres[0] != s->pf.gres[0] || nf.gres[1] != s->pf.gres[1] ||
         nf.gres[2] != s->pf.gres[2] || nf.z0 != s->pf.z0 || nf.nz != s->pf.nz)
         return fail(FSA_ERR_INVALID, "grid resolution / slab differ from the ones the solver was created with");
+    const int own_lo = s->pf.own_lo, own_hi = s->pf.own_hi;
     s->hp = *p;
     to_dev_params(*p, s->pf);
     to_dev_params(*p, s->pd);
+    s->pf.own_lo = s->pd.own_lo = own_lo;
+    s->pf.own_hi = s->pd.own_hi = own_hi;
     invalidate_order(s);
     return FSA_OK;
 }
@@ -784,6 +789,18 @@ int fsa_slab_unpack(fsa_solver *hs, const void *d_records, int count) {
     invalidate_order(s);
     s->count_valid = false;
     s->owned_from_sort = false;
+    return FSA_OK;
+}
+
+int fsa_slab_set_owned(fsa_solver *hs, const int own[2]) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s || !own) return fail(FSA_ERR_INVALID, "NULL argument");
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_set_owned needs a solver created with slab_nz > 0");
+    if (own[0] < s->pf.z0 || own[1] > s->pf.z0 + s->pf.nz || own[0] > own[1])
+        return fail(FSA_ERR_INVALID, "owned layers [%d, %d) outside the layers held [%d, %d)", own[0], own[1], s->pf.z0,
+                    s->pf.z0 + s->pf.nz);
+    s->pf.own_lo = s->pd.own_lo = own[0];
+    s->pf.own_hi = s->pd.own_hi = own[1];
     return FSA_OK;
 }
 

@@ -52,6 +52,9 @@ template <typename T> struct DevParams {
     int z0;        // first global cell layer held by this solver
     int nz;        // number of layers held (ghost layers included)
     int num_cells; // gres[0] * gres[1] * nz
+    // z-slab runs: global layers [own_lo, own_hi) whose particles need forces (density: one layer more on
+    // each side); what else the solver holds is halo, whose results nobody reads.  Default: everything.
+    int own_lo, own_hi;
 };
 
 __device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
@@ -93,6 +96,24 @@ template <typename T> __device__ __forceinline__ bool in_domain(const DevParams<
     return (double)x < (double)P.gmax[0] - FSA_EPSILON && (double)x > (double)P.gmin[0] + FSA_EPSILON &&
            (double)y < (double)P.gmax[1] - FSA_EPSILON && (double)y > (double)P.gmin[1] + FSA_EPSILON &&
            (double)z < (double)P.gmax[2] - FSA_EPSILON && (double)z > (double)P.gmin[2] + FSA_EPSILON;
+}
+
+// Is a particle in global cell layer gz needed (`margin` = 0 for the force pass, 1 for density)?
+template <typename T> __device__ __forceinline__ bool layer_needed(const DevParams<T> &P, int gz, int margin) {
+    return gz >= P.own_lo - margin && gz < P.own_hi + margin;
+}
+// A run of consecutive sorted particles from cell hlo to cell hhi (both in the grid): true when none of
+// its layers is needed.  The sorted order is (y, layer, x), so the run covers the layers from hlo's to
+// hhi's inside one y, or the tail of one y and the head of the next.
+template <typename T>
+__device__ __forceinline__ bool run_unneeded(const DevParams<T> &P, unsigned hlo, unsigned hhi, int margin) {
+    const unsigned gx = (unsigned)P.gres[0], nz = (unsigned)P.nz;
+    const int ylo = (int)(hlo / (gx * nz)), yhi = (int)(hhi / (gx * nz));
+    const int llo = (int)((hlo / gx) % nz), lhi = (int)((hhi / gx) % nz);
+    const int need_lo = P.own_lo - margin - P.z0, need_hi = P.own_hi + margin - P.z0;  // local layers
+    if (ylo == yhi) return lhi < need_lo || llo >= need_hi;
+    if (yhi == ylo + 1) return llo >= need_hi && lhi < need_lo;
+    return false;
 }
 
 // Kernel_Cubic, solver/sph_kernel_impl.cuh:32-40, from the squared norm d2 = x*x + y*y + z*z

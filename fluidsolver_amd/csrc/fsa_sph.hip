@@ -29,6 +29,11 @@ __global__ __launch_bounds__(kBlock) void density_kernel(DevParams<T> P, int n,
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index >= n) return;
     const Vec4<T> pi = posType[index];
+    {
+        int cx, cy, cz;
+        calc_grid_pos(P, pi.x, pi.y, pi.z, cx, cy, cz);
+        if (!layer_needed(P, cz, 1)) return;  // halo of a slab run
+    }
     const T rd_i = restDensity[index];
     const T dens = density_walk_global(P, index, pi, velMass[index].w, rd_i, posType, restDensity, cellStart);
     density[index] = dens;
@@ -52,6 +57,11 @@ __global__ __launch_bounds__(kBlock) void force_kernel(DevParams<T> P, int n, co
     ForceSelf<T> S;
     S.p = posType[index];
     if (unpack_int(S.p.w) != FSA_TYPE_FLUID) return;  // force[index] keeps its old value
+    {
+        int cx, cy, cz;
+        calc_grid_pos(P, S.p.x, S.p.y, S.p.z, cx, cy, cz);
+        if (!layer_needed(P, cz, 0)) return;  // halo of a slab run
+    }
     S.v = velMass[index];
     const T dens_i = density[index];
     S.pterm = pressure[index] / dens_i / dens_i;

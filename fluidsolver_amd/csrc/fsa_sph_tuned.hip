@@ -59,9 +59,9 @@ template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
 template <int ROWCAP, typename Shared>
 __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, int nb,
                                            const int *__restrict__ cellStart,
-                                           const int *__restrict__ sortedHash, Shared &sh) {
+                                           const int *__restrict__ sortedHash, Shared &sh, unsigned hlo,
+                                           unsigned hhi) {
     const int tid = threadIdx.x;
-    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
     const int C = P.num_cells;
     const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
     if (tid < 9) {
@@ -284,7 +284,10 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     const bool active = index < n;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
+    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+    // slab runs: a tile that lies entirely in the outer halo layer feeds nobody
+    if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -421,6 +424,9 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
+    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+    // slab runs: forces are only needed for the layers the solver owns
+    if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 0)) return;
 
     ForceSelf<float> S;
     S.p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     // a block without fluid particles (wall layers) has nothing to do
     if (!__syncthreads_or(active ? 1 : 0)) return;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh);
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
     if (active) {
         S.v = velMass[index];
         S.pterm = pd[index].x;

@@ -173,6 +173,9 @@ class HipSlabBackend:
     def set_scene_has_rigid(self, flag):
         self.solver.set_scene_has_rigid(flag)
 
+    def set_owned(self, own):
+        self.solver.slab_set_owned(own)
+
     def pack(self, own, keep, left, right, buf_left, cap_left, buf_right, cap_right):
         return self.solver.slab_pack(own, keep, left, right, buf_left.data_ptr(), cap_left, buf_right.data_ptr(),
                                      cap_right)
@@ -243,6 +246,7 @@ class SlabSolver:
         sub["uniqueId"] = np.ascontiguousarray(uid[mine])
         self.backend.upload(sub)
         self.backend.set_scene_has_rigid(bool((np.asarray(scene["type"]) == 4).any()))
+        self.backend.set_owned(own)
         self.peers = [p for p in (rank - 1, rank + 1) if 0 <= p < world]
         self.send_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
         self.recv_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}

@@ -232,6 +232,12 @@ int fsa_slab_record_bytes(fsa_solver *s, int *bytes);
  */
 int fsa_slab_pack(fsa_solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
                   void *d_send_left, int cap_left, void *d_send_right, int cap_right, int counts[4]);
+/*
+ * Tells the solver which of the layers it holds it owns, [own[0], own[1]).  From then on the density
+ * pass only covers particles within one layer of that range and the force pass the range itself (the
+ * halo beyond feeds nobody); density / pressure / force of the other particles held are unspecified.
+ */
+int fsa_slab_set_owned(fsa_solver *s, const int own[2]);
 /* Appends `count` records from device memory (written by a neighbour's fsa_slab_pack). */
 int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
 /* Overrides the scan of `type` that fsa_upload does: whether a TYPE_RIGID particle can ever be held by

@@ -42,6 +42,9 @@ class OracleSlabBackend:
     def set_scene_has_rigid(self, flag):
         pass
 
+    def set_owned(self, own):
+        pass
+
     def synchronize(self):
         pass
 
