@@ -223,6 +223,8 @@ void MultiphaseSPHSolver::Setup() {
         std::exit(EXIT_FAILURE);
     }
     SetupSPH();
+    // resume from a text checkpoint written by key 'b' (DumpSimulationDataText)
+    if (const char *resume = std::getenv("FSA_RESUME")) LoadSimulationDataText(resume);
     if (run_mode != SPH) {
         std::fprintf(stderr, "<RunMode> of the scene asks for a step this build does not have\n");
         std::exit(EXIT_FAILURE);

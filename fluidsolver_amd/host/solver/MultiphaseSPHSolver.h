@@ -4,7 +4,7 @@
 //
 // The reference's Setup() always selects its IISPH step; which step runs here is chosen at run time:
 // environment variable FSA_RUN_MODE ("SPH", the default and the only step this build has), or a
-// <RunMode> tag in the scene.  Two more optional scene tags exist for the WCSPH step, which has no wall
+// <RunMode> tag in the scene.  FSA_RESUME=<file> continues from a text checkpoint (key 'b').  Two more optional scene tags exist for the WCSPH step, which has no wall
 // response for TYPE_RIGID particles: <WallType> (particle type given to the boundary file's particles,
 // default 4 = TYPE_RIGID as LoadPO assigns), <WallRestDensity>, and <BoundaryMode> (0 verbatim
 // integration, 1 legacy clamp to the grid box).  <GridMin> / <GridMax> give a scene its own grid box

@@ -162,3 +162,30 @@ def test_headless_program_matches_python_binding(tmp_path, scene_id):
     assert np.array_equal(rows[:, 6].astype(int), s.get("type"))
     assert np.array_equal(rows[:, 9].astype(int), s.get("uniqueId"))
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_text_checkpoint_resume(tmp_path):
+    """10 frames in one go against 5 frames, text checkpoint (key 'b'), resume, 5 more frames.  The dump
+    prints six decimals, so the resumed run agrees to that precision, not bit for bit."""
+    exe = os.path.join(HOST, "bin", "particle_solver")
+    e = env_for(20)
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    e["FSA_DUMP_DIR"] = str(dump)
+    a, c = tmp_path / "a.bin", tmp_path / "c.bin"
+    subprocess.check_call([exe, "--frames", "10", "--save-final", str(a)], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    subprocess.check_call([exe, "--frames", "5", "--keys", "b"], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    ckpt = dump / "005.txt"
+    assert ckpt.exists()
+    e2 = dict(e, FSA_RESUME=str(ckpt))
+    subprocess.check_call([exe, "--frames", "5", "--save-final", str(c)], env=e2, stdout=subprocess.DEVNULL, timeout=300)
+    pa, _ = read_final(a)
+    pc, _ = read_final(c)
+    assert pa.shape == pc.shape
+    # both runs end in their own sorted order; compare as sets of points through a lexicographic sort
+    ka = np.lexsort((pa[:, 2], pa[:, 1], pa[:, 0]))
+    kc = np.lexsort((pc[:, 2], pc[:, 1], pc[:, 0]))
+    assert np.abs(np.sort(pa[:, 1]) - np.sort(pc[:, 1])).max() < 2e-5
+    assert np.abs(pa[ka].mean(0) - pc[kc].mean(0)).max() < 1e-6
