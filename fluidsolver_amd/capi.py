@@ -29,7 +29,7 @@ EXPORTS = (
     "fsa_sort_particles", "fsa_compute_pressure", "fsa_compute_force", "fsa_advect",
     "fsa_rigid_particle_volume", "fsa_step", "fsa_readback_pos_color", "fsa_get_buffer", "fsa_set_buffer",
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant",
-    "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned",
+    "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned", "fsa_slab_export_owned",
     "fsa_set_scene_has_rigid",
 )
 
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
                                                            C.POINTER(C.c_int)],
         "fsa_slab_unpack": [H, C.c_void_p, C.c_int],
         "fsa_slab_set_owned": [H, C.POINTER(C.c_int)],
+        "fsa_slab_export_owned": [H, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)],
         "fsa_set_scene_has_rigid": [H, C.c_int],
     }
     for name, args in protos.items():
@@ -303,6 +304,12 @@ class Solver:
 
     def slab_unpack(self, records_ptr, count):
         check(self.lib.fsa_slab_unpack(self._h, C.c_void_p(records_ptr), int(count)))
+
+    def slab_export_owned(self, own, records_ptr, cap) -> int:
+        n = C.c_int()
+        check(self.lib.fsa_slab_export_owned(self._h, (C.c_int * 2)(*own), C.c_void_p(records_ptr), int(cap),
+                                             C.byref(n)))
+        return n.value
 
     def slab_set_owned(self, own):
         check(self.lib.fsa_slab_set_owned(self._h, (C.c_int * 2)(*own)))

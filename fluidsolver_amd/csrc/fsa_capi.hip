@@ -777,6 +777,16 @@ int fsa_slab_pack(fsa_solver *hs, const int own[2], const int keep[2], const int
     return FSA_OK;
 }
 
+int fsa_slab_export_owned(fsa_solver *hs, const int own[2], void *d_records, int cap, int *count) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_export_owned needs a solver created with slab_nz > 0");
+    if (!own || !count || cap < 0 || (cap > 0 && !d_records)) return fail(FSA_ERR_INVALID, "bad argument");
+    TRY(launch_slab_export(s, own, d_records, cap, count));
+    if (*count > cap) return fail(FSA_ERR_CAPACITY, "%d owned particles for %d record slots", *count, cap);
+    return FSA_OK;
+}
+
 int fsa_slab_unpack(fsa_solver *hs, const void *d_records, int count) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);

@@ -162,6 +162,50 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
     }
 }
 
+// Every particle owned at the last sort (out-of-grid ones included) as a record; the solver's arrays
+// stay as they are.  One atomic per wavefront: this runs when the slabs are re-cut, not every step.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void slab_export_kernel(DevParams<T> P, int n, int all_owned, int own_lo, int own_hi,
+                                                             const int *__restrict__ sortedHash,
+                                                             const Vec4<T> *__restrict__ posType,
+                                                             const Vec4<T> *__restrict__ velMass,
+                                                             const T *__restrict__ restDensity,
+                                                             const int *__restrict__ uniqueId,
+                                                             const long long *__restrict__ key,
+                                                             SlabRecord<T> *__restrict__ out, int cap,
+                                                             int *__restrict__ counter) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool owned = false;
+    if (i < n) {
+        owned = all_owned != 0;
+        if (!owned) {
+            const unsigned h = (unsigned)sortedHash[i];
+            if (h == FSA_GRID_UNDEF) {
+                owned = true;
+            } else {
+                const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
+                owned = gz >= own_lo && gz < own_hi;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(owned);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (!owned) return;
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (slot >= cap) return;
+    SlabRecord<T> rec{};
+    rec.posType = posType[i];
+    rec.velMass = velMass[i];
+    rec.orderKey = key[i];
+    rec.restDensity = restDensity[i];
+    rec.uniqueId = uniqueId[i];
+    out[slot] = rec;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void slab_unpack_kernel(int count, int at, const SlabRecord<T> *__restrict__ recs,
                                                              Vec4<T> *__restrict__ posType,
@@ -292,6 +336,29 @@ int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int l
         if (rc) return rc;
     }
     FSA_HIP(hipMemcpyAsync(counts, s->b.slabCounters, 4 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    return FSA_OK;
+}
+
+int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *count) {
+    FSA_HIP(hipMemsetAsync(s->b.slabCounters, 0, 4 * sizeof(int), s->stream));
+    if (s->n > 0) {
+        ScopedTimer t(s, "slab_export");
+        const int c = s->cur, all_owned = s->owned_from_sort ? 0 : 1;
+        if (s->precision == FSA_PRECISION_F32)
+            hipLaunchKernelGGL(slab_export_kernel<float>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->pf, s->n,
+                               all_owned, own[0], own[1], s->b.sortedHash, (const float4 *)s->b.posType[c],
+                               (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.uniqueId[c],
+                               s->b.orderKey[c], (SlabRecord<float> *)recs, cap, s->b.slabCounters);
+        else
+            hipLaunchKernelGGL(slab_export_kernel<double>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->pd,
+                               s->n, all_owned, own[0], own[1], s->b.sortedHash, (const double4 *)s->b.posType[c],
+                               (const double4 *)s->b.velMass[c], (const double *)s->b.restDensity[c],
+                               s->b.uniqueId[c], s->b.orderKey[c], (SlabRecord<double> *)recs, cap,
+                               s->b.slabCounters);
+        FSA_HIP(hipGetLastError());
+    }
+    FSA_HIP(hipMemcpyAsync(count, s->b.slabCounters, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     FSA_HIP(hipStreamSynchronize(s->stream));
     return FSA_OK;
 }

@@ -131,6 +131,7 @@ int launch_slab_keys(Solver *s);
 int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
                      void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
 int launch_slab_unpack(Solver *s, const void *recs, int count);
+int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *count);
 int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
 int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);
 int launch_unpack_w(Solver *s, const void *src4, void *dst, int n, bool as_int);

@@ -138,6 +138,35 @@ class NeighbourTransport:
         return counts
 
 
+    def redistribute(self, chunks, record_bytes):
+        """chunks[d] = uint8 tensor of whole records for rank d (any rank, d != self.rank).  Returns
+        {source rank: uint8 tensor} of what the other ranks had for this one.  Used when the slabs are
+        re-cut; all ranks call it together."""
+        torch, dist = self.torch, self.dist
+        mine = torch.zeros(self.world, dtype=torch.int64, device=self.comm_device)
+        for d, t in chunks.items():
+            mine[d] = t.numel()
+        table = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(table, mine, group=self.group)
+        sends, recvs, got = [], [], {}
+        for d, t in chunks.items():
+            if d != self.rank and t.numel():
+                sends.append((d, t.cpu() if self.staged else t.contiguous()))
+        for src in range(self.world):
+            nb = int(table[src][self.rank].item())
+            if src != self.rank and nb:
+                got[src] = torch.empty(nb, dtype=torch.uint8, device=self.comm_device)
+                recvs.append((src, got[src]))
+        self._batch(sends, recvs)
+        return got
+
+    def sum_over_ranks(self, values):
+        """element-wise sum of an integer vector over all ranks, as a numpy array"""
+        t = self.torch.as_tensor(np.asarray(values, dtype=np.int64)).to(self.comm_device)
+        self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+
 # ------------------------------------------------------------------------------------------------
 # local solver on the GPU
 # ------------------------------------------------------------------------------------------------
@@ -182,6 +211,9 @@ class HipSlabBackend:
 
     def unpack(self, buf, count):
         self.solver.slab_unpack(buf.data_ptr(), count)
+
+    def export_owned(self, own, buf, cap):
+        return self.solver.slab_export_owned(own, buf.data_ptr(), cap)
 
     def step_local(self):
         self.solver.step(1)
@@ -239,21 +271,95 @@ class SlabSolver:
         widest = max(int(hist[max(c - 2 * halo, 0):c + 2 * halo].sum()) for c in self.layout.cuts[1:-1]) \
             if world > 1 else 0
         self.record_cap = int(widest * slack) + 4096
+        self.params, self.factory, self.halo, self.slack = P, backend_factory, halo, slack
+        self.geo = geo
+        self.has_rigid = bool((np.asarray(scene["type"]) == 4).any())
         self.backend = backend_factory(P, held, self.capacity)
         uid = np.asarray(scene.get("uniqueId", np.arange(len(pos))), dtype=np.int32)
         sub = {k: np.ascontiguousarray(np.asarray(scene[k])[mine]) for k in ("pos", "vel", "type", "mass",
                                                                              "restDensity")}
         sub["uniqueId"] = np.ascontiguousarray(uid[mine])
         self.backend.upload(sub)
-        self.backend.set_scene_has_rigid(bool((np.asarray(scene["type"]) == 4).any()))
+        self.backend.set_scene_has_rigid(self.has_rigid)
         self.backend.set_owned(own)
         self.peers = [p for p in (rank - 1, rank + 1) if 0 <= p < world]
+        self._make_exchange_buffers()
+        self.lost = 0
+        self.sent_records = 0
+        self.recuts = 0
+
+    def _make_exchange_buffers(self):
         self.send_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
         self.recv_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
         self._null = self.backend.make_buffer(1)
-        self.lost = 0
-        self.sent_records = 0
-        self.exchange_seconds = 0.0
+
+    def _record_layers(self, rec):
+        """global cell layer of each record (rows of a (count, record_bytes) uint8 tensor), -1 outside"""
+        import torch
+        pos = rec[:, :12].contiguous().view(torch.float32).view(-1, 3)
+        f32 = torch.float32
+        lo = torch.tensor([float(v) for v in self.geo["vmin"]], dtype=f32, device=pos.device)
+        hi = torch.tensor([float(v) for v in self.geo["vmax"]], dtype=f32, device=pos.device)
+        dx = torch.tensor(float(self.geo["dx"]), dtype=f32, device=pos.device)
+        res = torch.tensor(self.gridres, dtype=torch.int64, device=pos.device)
+        p64 = pos.double()
+        inside = ((p64 < hi.double() - 1e-10) & (p64 > lo.double() + 1e-10)).all(1)
+        cell = torch.floor((pos - lo) / dx).long()
+        inside &= ((cell >= 0) & (cell < res)).all(1)
+        return torch.where(inside, cell[:, 2], torch.full_like(cell[:, 2], -1))
+
+    def rebalance(self):
+        """Re-cut the slabs so that every rank owns about the same number of particles again (all ranks
+        call this together, between two steps).  Every particle goes to its new owner with its order
+        key; the next exchange hands out the halo copies.  Returns True if the cuts changed."""
+        import torch
+        if self.world == 1:
+            return False
+        with self.backend.stream_ctx():
+            b, rb = self.backend, self.backend.record_bytes
+            cap = max(b.n, 1)
+            buf = b.make_buffer(cap)
+            cnt = b.export_owned(self.own, buf, cap)
+            rec = buf[:cnt * rb].view(cnt, rb)
+            layer = self._record_layers(rec)
+            gz = self.gridres[2]
+            local_hist = torch.bincount(layer[layer >= 0], minlength=gz).cpu().numpy()
+            outside = int((layer < 0).sum().item())
+            hist = self.transport.sum_over_ranks(np.concatenate([local_hist, [outside]]))
+            hist, n_outside = hist[:gz], int(hist[gz])
+            cuts = balanced_cuts(hist, self.world, self.halo + 1)
+            if cuts == self.layout.cuts:
+                return False
+            bounds = torch.tensor(cuts[1:-1], dtype=torch.int64, device=layer.device)
+            owner = torch.bucketize(layer, bounds, right=True)
+            owner = torch.where(layer < 0, torch.full_like(owner, self.rank), owner)
+            chunks = {d: rec[owner == d].reshape(-1) for d in range(self.world)}
+            got = self.transport.redistribute({d: t for d, t in chunks.items() if d != self.rank}, rb)
+            got[self.rank] = chunks[self.rank]
+            # new layout, new local solver
+            self.layout = SlabLayout(gz, cuts, self.halo)
+            self.own, self.held_layers = self.layout.own(self.rank), self.layout.held(self.rank)
+            pre = np.concatenate([[0], np.cumsum(hist)])
+            held_counts = [pre[self.layout.held(r)[1]] - pre[self.layout.held(r)[0]] for r in range(self.world)]
+            self.capacity = int(max(held_counts) * self.slack) + n_outside + 4096
+            widest = max(int(hist[max(c - 2 * self.halo, 0):c + 2 * self.halo].sum()) for c in cuts[1:-1])
+            self.record_cap = int(widest * self.slack) + 4096
+            b.synchronize()
+            b.close()
+        self.backend = self.factory(self.params, self.held_layers, self.capacity)
+        self.backend.set_scene_has_rigid(self.has_rigid)
+        self.backend.set_owned(self.own)
+        with self.backend.stream_ctx():
+            for src in sorted(got):
+                t = got[src]
+                if t.numel():
+                    dev = self.backend.make_buffer(1).device
+                    t = t.to(dev).contiguous()
+                    self.backend.unpack(t, t.numel() // rb)
+            self.backend.synchronize()
+        self._make_exchange_buffers()
+        self.recuts += 1
+        return True
 
     def exchange(self):
         """migration and halo refresh in one neighbour exchange"""

@@ -238,6 +238,13 @@ int fsa_slab_pack(fsa_solver *s, const int own[2], const int keep[2], const int 
  * halo beyond feeds nobody); density / pressure / force of the other particles held are unspecified.
  */
 int fsa_slab_set_owned(fsa_solver *s, const int own[2]);
+/*
+ * Writes every particle this solver owned at the last sort (out-of-grid ones included; all particles
+ * if no sort has run) as a record to d_records without changing the solver: what a driver needs to
+ * re-cut the slabs (it then builds new solvers and hands each its particles with fsa_slab_unpack).
+ * Synchronises.
+ */
+int fsa_slab_export_owned(fsa_solver *s, const int own[2], void *d_records, int cap, int *count);
 /* Appends `count` records from device memory (written by a neighbour's fsa_slab_pack). */
 int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
 /* Overrides the scan of `type` that fsa_upload does: whether a TYPE_RIGID particle can ever be held by

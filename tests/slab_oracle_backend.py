@@ -27,7 +27,9 @@ class OracleSlabBackend:
         self.gres = [int(v) for v in self.p.gridres]
         self.num_cells = self.gres[0] * self.gres[1] * self.gres[2]
         self.held, self.capacity = held, capacity
-        self.a = {}
+        self.a = {"pos": np.zeros((0, 3), np.float32), "vel": np.zeros((0, 3), np.float32),
+                  "type": np.zeros(0, np.int32), "mass": np.zeros(0, np.float32),
+                  "restDensity": np.zeros(0, np.float32), "uniqueId": np.zeros(0, np.int32)}
         self.key = np.zeros(0, np.int64)
         self.sorted_hash = None
         self.res = {}
@@ -108,6 +110,27 @@ class OracleSlabBackend:
         self.key = self.key[k]
         self.sorted_hash = None
         return int(k.sum()), int(l.sum()), int(r.sum()), int(lost.sum())
+
+    def export_owned(self, own, buf, cap):
+        n = self.n
+        if self.sorted_hash is None:
+            owned = np.ones(n, bool)
+        else:
+            was = self._layer_of_hash(self.sorted_hash)
+            owned = (was < 0) | ((was >= own[0]) & (was < own[1]))
+        m = int(owned.sum())
+        assert m <= cap
+        rec = np.zeros(m, RECORD)
+        rec["posType"][:, :3] = self.a["pos"][owned]
+        rec["posType"][:, 3] = self.a["type"][owned].view(np.float32)
+        rec["velMass"][:, :3] = self.a["vel"][owned]
+        rec["velMass"][:, 3] = self.a["mass"][owned]
+        rec["orderKey"] = self.key[owned]
+        rec["restDensity"] = self.a["restDensity"][owned]
+        rec["uniqueId"] = self.a["uniqueId"][owned]
+        if m:
+            buf.numpy()[:m * RECORD.itemsize] = rec.view(np.uint8).reshape(-1)
+        return m
 
     def unpack(self, buf, count):
         if count == 0:

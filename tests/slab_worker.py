@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--backend", choices=["oracle", "hip"], required=True)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--recut-at", type=int, default=0, help="re-cut the slabs after this many steps")
     a = ap.parse_args()
 
     import torch
@@ -53,12 +54,24 @@ def main():
         device = torch.device("cuda", 0)
         factory = lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, a.variant)  # noqa: E731
     tr = slabs.NeighbourTransport(a.rank, a.world, device)
-    ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory)
-    ss.step(a.steps)
+    # with --recut-at the run starts from deliberately lopsided cuts, so that the re-cut has work to do
+    cuts = None
+    if a.recut_at:
+        gz = slabs.derive_grid(sc["params"])["gridres"][2]
+        cuts = [0] + [3 * (r + 1) for r in range(a.world - 1)] + [gz]
+    ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts)
+    if a.recut_at:
+        ss.step(a.recut_at)
+        changed = ss.rebalance()
+        assert changed, "the lopsided cuts should have been replaced"
+        ss.step(a.steps - a.recut_at)
+    else:
+        ss.step(a.steps)
     out = ss.owned()
     out["cuts"] = np.asarray(ss.layout.cuts)
     out["lost"] = np.asarray(ss.lost)
     out["sent"] = np.asarray(ss.sent_records)
+    out["owned_count"] = np.asarray(len(out["uniqueId"]))
     np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **out)
     ss.close()
     dist.barrier()

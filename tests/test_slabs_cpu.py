@@ -24,11 +24,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(world, backend, steps, out, timeout=600, variant=2):
+def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "--rank", str(r), "--world",
                                str(world), "--port", str(port), "--out", str(out), "--backend", backend, "--steps",
-                               str(steps), "--variant", str(variant)]) for r in range(world)]
+                               str(steps), "--variant", str(variant), "--recut-at", str(recut_at)])
+             for r in range(world)]
     try:
         codes = [p.wait(timeout=timeout) for p in procs]
     finally:
@@ -87,6 +88,20 @@ def test_slab_run_equals_undivided_run(orc32, tmp_path, world):
     assert_same_bits(uid, got, ref)
     cuts = parts[0]["cuts"]
     assert len(cuts) == world + 1 and all(np.diff(cuts) >= slabs.HALO + 1)
+
+
+def test_recut_mid_run_keeps_the_run_bit_identical(orc32, tmp_path):
+    """start from lopsided cuts, re-cut after 10 of 25 steps (particles move to other ranks, some not to a
+    neighbour): still the undivided run, and the ranks end up balanced"""
+    steps = 25
+    parts = run_ranks(3, "oracle", steps, tmp_path, recut_at=10)
+    assert sum(int(p["lost"]) for p in parts) == 0
+    sc, ref = undivided(orc32, steps)
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, ref)
+    counts = np.array([int(p["owned_count"]) for p in parts], float)
+    assert counts.max() / counts.mean() < 1.35
+    assert list(parts[0]["cuts"]) != [0, 3, 6, int(parts[0]["cuts"][-1])]
 
 
 def test_balanced_cuts():

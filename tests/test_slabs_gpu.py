@@ -62,6 +62,18 @@ def test_two_ranks_equal_plain_solver(tmp_path, orc32, variant):
     assert rel_err(got["pos"], orc_ref["pos"][ro], scale=1.0) < tol
 
 
+def test_recut_two_ranks_equal_plain_solver(tmp_path):
+    """lopsided cuts, re-cut after 10 of 25 steps through fsa_slab_export_owned: still the plain run's bits"""
+    from slab_worker import test_scene
+    parts = run_ranks(2, "hip", STEPS, tmp_path, variant=2, recut_at=10)
+    assert sum(int(p["lost"]) for p in parts) == 0
+    uid, got = merged(parts)
+    ref = plain_gpu_run(test_scene(), STEPS, 2)
+    assert_same_bits(uid, got, ref)
+    counts = np.array([int(p["owned_count"]) for p in parts], float)
+    assert counts.max() / counts.mean() < 1.2
+
+
 def test_slab_solver_rejects_static_attributes():
     from slab_worker import test_scene
     sc = test_scene()
