@@ -207,6 +207,33 @@ def dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, wall_type=TYPE_BOUND
     return sc
 
 
+def double_dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.005, obstacles=2) -> dict:
+    """BASELINE config 4 in small: two nx*ny*nz fluid blocks at the two x ends of the tank and `obstacles`
+    box obstacles between them (filled TYPE_BOUNDARY lattices, the generator of BoundaryGenerator 'Cube',
+    solver/ParticleGenerator.h:27-43), staggered in z so that the flow is not symmetric along z."""
+    s = F32(spacing)
+    g = dam_break_geometry(nx, ny, nz, tank_x_factor, head_room, spacing, 1)
+    lo, hi = np.array(g["fluid_lo"]), np.array(g["fluid_hi"])
+    tank = np.array(g["tank_hi"])
+    ext = hi - lo
+    a = fluid_block(lo, hi, s, 1000.0, color=(0.2, 0.4, 1, 1), group=0)
+    shift = np.array([tank[0] - 2 * lo[0] - (nx - 1) * float(s), 0.0, 0.0])
+    b = fluid_block(lo + shift, hi + shift, s, 1000.0, color=(1, 0.4, 0.2, 1), group=1)
+    parts = [a, b, open_box(g["tank_lo"], g["tank_hi"], s, group=2, ptype=TYPE_BOUNDARY,
+                            mass=rigid_mass(s, 1000.0), rest_density=1000.0)]
+    side = max(4 * float(s), 0.15 * ext[2])
+    for k in range(obstacles):
+        cx = tank[0] * (k + 1) / (obstacles + 1)
+        cz = lo[2] + ext[2] * (0.25 if k % 2 == 0 else 0.75)
+        o_lo = (cx - side / 2, lo[1], cz - side / 2)
+        o_hi = (cx + side / 2, lo[1] + 0.5 * ext[1], cz + side / 2)
+        parts.append(cube(o_lo, o_hi, s, normal=(0, 1, 0), group=3 + k, ptype=TYPE_BOUNDARY,
+                          mass=rigid_mass(s, 1000.0), rest_density=1000.0))
+    sc = _finish(parts, g["params"])
+    sc["n_fluid"] = len(a["pos"]) + len(b["pos"])
+    return sc
+
+
 def ball_drop(center=(0.0, 0.30, 0.0), radius=0.10, floor=True) -> dict:
     """Ball drop: the lattice points (spacing 0.005) inside a sphere (ball.raw is a unit sphere; x0.1),
     in the shipped grid box with the shipped scene parameters, above a TYPE_BOUNDARY floor plate."""

@@ -63,6 +63,8 @@ SCENES = {
     "small_dam_walls": lambda: small_dam(),
     "small_dam_verbatim": lambda: small_dam(seed=99, walls=True, mode=0),
     "edge": edge_scene,
+    "double_dam_obstacles": lambda: scenes.jittered(scenes.double_dam_break(10, 10, 12, tank_x_factor=3.0), seed=3,
+                                                    pos_jitter=0.2, vel_scale=1.0, fluid_only=True),
 }
 
 
