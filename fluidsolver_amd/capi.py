@@ -31,6 +31,9 @@ EXPORTS = (
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant",
     "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned", "fsa_slab_export_owned",
     "fsa_set_scene_has_rigid",
+    "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
+    "fsa_solve_divergence_stiff", "fsa_apply_pstiff", "fsa_update_position", "fsa_update_velocities",
+    "fsa_correct_density_error", "fsa_correct_divergence_error", "fsa_setup_dfsph", "fsa_step_dfsph",
 )
 
 
@@ -46,7 +49,7 @@ class Params(C.Structure):
         ("viscosity", C.c_double), ("spacing", C.c_double), ("smoothradius", C.c_double),
         ("kspikydiff", C.c_double), ("kernel_cubic", C.c_double), ("kernel_cubic_gradient", C.c_double),
         ("pressureK", C.c_double), ("boundary_visc", C.c_double), ("acceleration_limit", C.c_double),
-        ("boundary_mode", C.c_int), ("slab_z0", C.c_int), ("slab_nz", C.c_int),
+        ("boundary_mode", C.c_int), ("slab_z0", C.c_int), ("slab_nz", C.c_int), ("kpoly6", C.c_double),
     ]
 
     @property
@@ -124,6 +127,11 @@ def load() -> C.CDLL:
         "fsa_slab_set_owned": [H, C.POINTER(C.c_int)],
         "fsa_slab_export_owned": [H, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)],
         "fsa_set_scene_has_rigid": [H, C.c_int],
+        "fsa_compute_density_alpha": [H], "fsa_compute_non_pressure_force": [H], "fsa_solve_density_stiff": [H],
+        "fsa_solve_divergence_stiff": [H], "fsa_apply_pstiff": [H], "fsa_update_position": [H],
+        "fsa_update_velocities": [H], "fsa_setup_dfsph": [H], "fsa_step_dfsph": [H, C.c_int],
+        "fsa_correct_density_error": [H, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)],
+        "fsa_correct_divergence_error": [H, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)],
     }
     for name, args in protos.items():
         f = getattr(lib, name)
@@ -170,6 +178,7 @@ BUFFERS = {
     "particleHash": ("i", 1), "particleIndex": ("i", 1),
     "gridCellStart": ("c", 0), "gridCellEnd": ("c", 0), "cellStartDense": ("c", 1),
     "orderKey": ("l", 1),
+    "DF_factor": ("r", 1), "pstiff": ("r", 1), "error": ("r", 1),
 }
 
 
@@ -285,6 +294,27 @@ class Solver:
     def synchronize(self): check(self.lib.fsa_synchronize(self._h))
     def set_stream(self, stream_ptr): check(self.lib.fsa_set_stream(self._h, C.c_void_p(stream_ptr)))
     def set_variant(self, v: int): check(self.lib.fsa_set_variant(self._h, int(v)))
+
+    # -- DFSPH ------------------------------------------------------------------------
+    def compute_density_alpha(self): check(self.lib.fsa_compute_density_alpha(self._h))
+    def compute_non_pressure_force(self): check(self.lib.fsa_compute_non_pressure_force(self._h))
+    def solve_density_stiff(self): check(self.lib.fsa_solve_density_stiff(self._h))
+    def solve_divergence_stiff(self): check(self.lib.fsa_solve_divergence_stiff(self._h))
+    def apply_pstiff(self): check(self.lib.fsa_apply_pstiff(self._h))
+    def update_position(self): check(self.lib.fsa_update_position(self._h))
+    def update_velocities(self): check(self.lib.fsa_update_velocities(self._h))
+    def setup_dfsph(self): check(self.lib.fsa_setup_dfsph(self._h))
+    def step_dfsph(self, nsteps: int = 1): check(self.lib.fsa_step_dfsph(self._h, int(nsteps)))
+
+    def correct_density_error(self, maxiter=5, ethres=1.0):
+        it, e = C.c_int(), C.c_double()
+        check(self.lib.fsa_correct_density_error(self._h, int(maxiter), float(ethres), C.byref(it), C.byref(e)))
+        return it.value, e.value
+
+    def correct_divergence_error(self, maxiter=5, ethres=1.0):
+        it, e = C.c_int(), C.c_double()
+        check(self.lib.fsa_correct_divergence_error(self._h, int(maxiter), float(ethres), C.byref(it), C.byref(e)))
+        return it.value, e.value
 
     # -- z-slab decomposition --------------------------------------------------------
     @property

@@ -70,6 +70,7 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.sr = (T)h.smoothradius;
     d.kspikydiff = (T)h.kspikydiff;
     d.kernel_cubic = (T)h.kernel_cubic;
+    d.kpoly6 = (T)h.kpoly6;
     d.pressureK = (T)h.pressureK;
     d.boundary_visc = (T)h.boundary_visc;
     d.accel_limit = (T)h.acceleration_limit;
@@ -104,7 +105,8 @@ static int check_params(const fsa_params *p) {
 static void free_all(Solver *s) {
     Buffers &b = s->b;
     void *ptrs[] = {b.posType[0], b.posType[1], b.velMass[0], b.velMass[1], b.restDensity[0], b.restDensity[1],
-                    b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.pd, b.hash, b.slot,
+                    b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.v_star_alt, b.DF_factor, b.pstiff,
+                    b.error, b.reduce_tmp, b.pd, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
@@ -196,6 +198,7 @@ int fsa_derive_params(fsa_params *p, int precision, double spacing, double smoot
         p->kspikydiff = (float)(-45.0f / (3.141592 * (double)powf(sr, 6.0f)));
         p->kernel_cubic = (float)(1 / 3.141593 / pow((double)(sr / 2), 3.0));
         p->kernel_cubic_gradient = (float)(1.5 / (double)3.141593f / pow((double)(sr / 2), 4.0));
+        p->kpoly6 = (float)(315.0f / (64.0f * 3.141592 * (double)powf(sr, 9.0f)));
     } else if (precision == FSA_PRECISION_F64) {
         const double sr = spacing * smoothratio;
         p->spacing = spacing;
@@ -209,6 +212,7 @@ int fsa_derive_params(fsa_params *p, int precision, double spacing, double smoot
         p->kspikydiff = -45.0f / (3.141592 * pow(sr, 6.0));
         p->kernel_cubic = 1 / 3.141593 / pow(sr / 2, 3.0);
         p->kernel_cubic_gradient = 1.5 / (double)3.141593f / pow(sr / 2, 4.0);
+        p->kpoly6 = 315.0f / (64.0f * 3.141592 * pow(sr, 9.0));
     } else {
         return fail(FSA_ERR_INVALID, "unknown precision %d", precision);
     }
@@ -259,6 +263,11 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.pressure, N * R, true);  // MultiphaseSPHSolver.cpp:975 does clear this one
     ALLOC(b.force, N * 3 * R, true);
     ALLOC(b.v_star, N * 3 * R, true);
+    ALLOC(b.v_star_alt, N * 3 * R, true);
+    ALLOC(b.DF_factor, N * R, true);
+    ALLOC(b.pstiff, N * R, true);
+    ALLOC(b.error, N * R, true);
+    ALLOC(b.reduce_tmp, 2048 * sizeof(double), true);
     ALLOC(b.pd, N * 2 * R, true);
     ALLOC(b.hash, N * sizeof(int), true);
     ALLOC(b.slot, N * sizeof(int), true);
@@ -593,6 +602,9 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
     if (k == "v_star") { TRY(want(N * 3 * R)); return copy_out(s, s->b.v_star, dst, bytes); }
     if (k == "density") { TRY(want(N * R)); return copy_out(s, s->b.density, dst, bytes); }
     if (k == "pressure") { TRY(want(N * R)); return copy_out(s, s->b.pressure, dst, bytes); }
+    if (k == "DF_factor") { TRY(want(N * R)); return copy_out(s, s->b.DF_factor, dst, bytes); }
+    if (k == "pstiff") { TRY(want(N * R)); return copy_out(s, s->b.pstiff, dst, bytes); }
+    if (k == "error") { TRY(want(N * R)); return copy_out(s, s->b.error, dst, bytes); }
     if (k == "restDensity") { TRY(want(N * R)); return copy_out(s, s->b.restDensity[c], dst, bytes); }
     if (k == "uniqueId") { TRY(want(N * sizeof(int))); return copy_out(s, s->b.uniqueId[c], dst, bytes); }
     if (k == "orderKey") {
@@ -666,6 +678,9 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     if (k == "v_star") return plain(s->b.v_star, N * 3 * R);
     if (k == "density") return plain(s->b.density, N * R);
     if (k == "pressure") return plain(s->b.pressure, N * R);
+    if (k == "DF_factor") return plain(s->b.DF_factor, N * R);
+    if (k == "pstiff") return plain(s->b.pstiff, N * R);
+    if (k == "error") return plain(s->b.error, N * R);
     if (k == "restDensity") return plain(s->b.restDensity[c], N * R);
     if (k == "pos" || k == "vel") {
         TRY(want(N * 3 * R));
@@ -740,6 +755,89 @@ int fsa_timing_read(fsa_solver *hs, fsa_kernel_time *out, int cap, int *count) {
         w++;
     }
     *count = w;
+    return FSA_OK;
+}
+
+// ---- DFSPH -------------------------------------------------------------------------------------
+#define DFSPH_ENTRY(name, launcher, needs_sort)                                                      \
+    int name(fsa_solver *hs) {                                                                       \
+        Solver *s = reinterpret_cast<Solver *>(hs);                                                  \
+        NEED(s);                                                                                     \
+        if (s->slab) return fail(FSA_ERR_INVALID, #name " is not available in a slab solver");       \
+        if (needs_sort && !s->sorted_valid) return fail(FSA_ERR_INVALID, #name " needs a sorted state"); \
+        return launcher(s);                                                                          \
+    }
+DFSPH_ENTRY(fsa_compute_density_alpha, launch_density_alpha, true)
+DFSPH_ENTRY(fsa_compute_non_pressure_force, launch_non_pressure_force, true)
+DFSPH_ENTRY(fsa_solve_density_stiff, launch_solve_density_stiff, true)
+DFSPH_ENTRY(fsa_solve_divergence_stiff, launch_solve_divergence_stiff, true)
+DFSPH_ENTRY(fsa_apply_pstiff, launch_apply_pstiff, true)
+DFSPH_ENTRY(fsa_update_velocities, launch_update_velocities, false)
+#undef DFSPH_ENTRY
+
+int fsa_update_position(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (s->slab) return fail(FSA_ERR_INVALID, "fsa_update_position is not available in a slab solver");
+    TRY(launch_update_position(s));
+    // positions moved: the cell ranges no longer describe them
+    s->sorted_valid = false;
+    s->hash_valid = false;
+    s->perm_valid = false;
+    return FSA_OK;
+}
+
+int fsa_correct_density_error(fsa_solver *hs, int maxiter, double ethres, int *iterations, double *last_error) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    int iter = 0;
+    double error = 0.0;
+    while (iter < maxiter) {
+        TRY(fsa_solve_density_stiff(hs));
+        TRY(launch_max_error(s, -9999.0, &error));  // solver/sph_solver.cu:176
+        if (error < ethres) break;
+        TRY(fsa_apply_pstiff(hs));
+        iter++;
+    }
+    TRY(fsa_update_position(hs));
+    if (iterations) *iterations = iter;
+    if (last_error) *last_error = error;
+    return FSA_OK;
+}
+
+int fsa_correct_divergence_error(fsa_solver *hs, int maxiter, double ethres, int *iterations, double *last_error) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    int iter = 0;
+    double error = 0.0;
+    TRY(fsa_solve_divergence_stiff(hs));  // the extra first launch of solver/sph_solver.cu:226
+    while (iter < maxiter) {
+        TRY(fsa_solve_divergence_stiff(hs));
+        TRY(launch_max_error(s, 0.0, &error));
+        if (error < ethres) break;
+        TRY(fsa_apply_pstiff(hs));
+        iter++;
+    }
+    TRY(fsa_update_velocities(hs));
+    if (iterations) *iterations = iter;
+    if (last_error) *last_error = error;
+    return FSA_OK;
+}
+
+int fsa_setup_dfsph(fsa_solver *hs) {
+    TRY(fsa_sort_particles(hs));
+    return fsa_compute_density_alpha(hs);
+}
+
+int fsa_step_dfsph(fsa_solver *hs, int nsteps) {
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    for (int k = 0; k < nsteps; k++) {
+        TRY(fsa_compute_non_pressure_force(hs));
+        TRY(fsa_correct_density_error(hs, 5, 1.0, nullptr, nullptr));
+        TRY(fsa_sort_particles(hs));
+        TRY(fsa_compute_density_alpha(hs));
+        TRY(fsa_correct_divergence_error(hs, 5, 1.0, nullptr, nullptr));
+    }
     return FSA_OK;
 }
 

@@ -45,6 +45,7 @@ template <typename T> struct DevParams {
     T sr;          // smoothradius
     T kspikydiff;
     T kernel_cubic;
+    T kpoly6;
     T pressureK;
     T boundary_visc;
     T accel_limit;

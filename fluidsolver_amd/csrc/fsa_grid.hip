@@ -14,6 +14,8 @@
 //   4. rank         : inside each cell, rank = number of entries with a smaller source index, which
 //                     turns the arbitrary arrival order into the stable one, deterministically.
 //   5. reorder      : gather the hot arrays through the permutation into the other buffer copy.
+#include <utility>
+
 #include "fsa_solver.h"
 
 namespace fsa {
@@ -234,10 +236,12 @@ __global__ __launch_bounds__(kBlock) void reorder_kernel(int n, const int *__res
                                                          const Vec4<T> *__restrict__ velMassIn,
                                                          const T *__restrict__ restDensityIn,
                                                          const int *__restrict__ uniqueIdIn,
+                                                         const Vec3<T> *__restrict__ vStarIn,
                                                          Vec4<T> *__restrict__ posTypeOut,
                                                          Vec4<T> *__restrict__ velMassOut,
                                                          T *__restrict__ restDensityOut,
-                                                         int *__restrict__ uniqueIdOut) {
+                                                         int *__restrict__ uniqueIdOut,
+                                                         Vec3<T> *__restrict__ vStarOut) {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     const int i = sortedIndex[p];
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void reorder_kernel(int n, const int *__res
     velMassOut[p] = velMassIn[i];
     restDensityOut[p] = restDensityIn[i];
     uniqueIdOut[p] = uniqueIdIn[i];
+    vStarOut[p] = vStarIn[i];  // sortedV_star, solver/sph_kernel_impl.cuh:168
 }
 
 // gridCellStart / gridCellEnd in the reference's format (solver/sph_kernel_impl.cuh:151-163 after the
@@ -330,14 +335,17 @@ int launch_reorder(Solver *s) {
     if (s->precision == FSA_PRECISION_F32)
         hipLaunchKernelGGL(reorder_kernel<float>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
                            s->b.sortedIndex, (const float4 *)s->b.posType[in], (const float4 *)s->b.velMass[in],
-                           (const float *)s->b.restDensity[in], s->b.uniqueId[in], (float4 *)s->b.posType[out],
-                           (float4 *)s->b.velMass[out], (float *)s->b.restDensity[out], s->b.uniqueId[out]);
+                           (const float *)s->b.restDensity[in], s->b.uniqueId[in], (const Vec3<float> *)s->b.v_star,
+                           (float4 *)s->b.posType[out], (float4 *)s->b.velMass[out], (float *)s->b.restDensity[out],
+                           s->b.uniqueId[out], (Vec3<float> *)s->b.v_star_alt);
     else
         hipLaunchKernelGGL(reorder_kernel<double>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
                            s->b.sortedIndex, (const double4 *)s->b.posType[in], (const double4 *)s->b.velMass[in],
-                           (const double *)s->b.restDensity[in], s->b.uniqueId[in], (double4 *)s->b.posType[out],
-                           (double4 *)s->b.velMass[out], (double *)s->b.restDensity[out], s->b.uniqueId[out]);
+                           (const double *)s->b.restDensity[in], s->b.uniqueId[in], (const Vec3<double> *)s->b.v_star,
+                           (double4 *)s->b.posType[out], (double4 *)s->b.velMass[out], (double *)s->b.restDensity[out],
+                           s->b.uniqueId[out], (Vec3<double> *)s->b.v_star_alt);
     FSA_HIP(hipGetLastError());
+    std::swap(s->b.v_star, s->b.v_star_alt);
     if (s->slab) return launch_slab_keys(s);
     return FSA_OK;
 }

@@ -26,7 +26,13 @@ struct Buffers {
     void *density = nullptr;
     void *pressure = nullptr;
     void *force = nullptr;   // tight 3-vectors
-    void *v_star = nullptr;  // tight 3-vectors
+    void *v_star = nullptr;  // tight 3-vectors; reordered with the particles like the hot set ...
+    void *v_star_alt = nullptr;  // ... into this copy, then the two pointers swap
+    // DFSPH step
+    void *DF_factor = nullptr;
+    void *pstiff = nullptr;
+    void *error = nullptr;
+    void *reduce_tmp = nullptr;  // block maxima of error[]
     void *pd = nullptr;      // {pressure / density^2, density} pairs for the tuned force pass
     // neighbour search
     int *hash = nullptr;         // cell of particle i (device order before the sort)
@@ -121,6 +127,14 @@ int launch_density(Solver *s);
 int launch_force(Solver *s);
 int launch_advect(Solver *s);
 int launch_rigid_volume(Solver *s);
+int launch_density_alpha(Solver *s);
+int launch_non_pressure_force(Solver *s);
+int launch_solve_density_stiff(Solver *s);
+int launch_solve_divergence_stiff(Solver *s);
+int launch_apply_pstiff(Solver *s);
+int launch_update_position(Solver *s);
+int launch_update_velocities(Solver *s);
+int launch_max_error(Solver *s, double start, double *out);  // synchronises
 int launch_density_tuned(Solver *s);
 int launch_force_tuned(Solver *s);
 int debug_time_pass(Solver *s, int which, int ablate, int reps);

@@ -691,7 +691,7 @@ int debug_time_pass(Solver *s, int which, int ablate, int reps) {
             g_out1 = s->b.tmpHash;
             rc = launch_density_tuned(s);
         } else {
-            g_out0 = s->b.v_star;
+            g_out0 = s->b.v_star_alt;
             rc = launch_force_tuned(s);
         }
     }

@@ -216,10 +216,24 @@ void MultiphaseSPHSolver::SetupSPH() {
     }
 }
 
+// SetupDFSPH, solver/sph_solver.cpp:102-106
+void MultiphaseSPHSolver::SetupDFSPH() {
+    SetupFluidScene();
+    run_mode = DFSPH;
+    if (numParticles > 0) {
+        check(fsa_setup_dfsph(device), "SetupDFSPH");
+        CopyPosColorFromDevice();
+    }
+}
+
 void MultiphaseSPHSolver::Setup() {
     const char *mode = std::getenv("FSA_RUN_MODE");
+    if (mode && std::strcmp(mode, "DFSPH") == 0) {
+        SetupDFSPH();
+        return;
+    }
     if (mode && std::strcmp(mode, "SPH") != 0) {
-        std::fprintf(stderr, "FSA_RUN_MODE=%s: only the WCSPH step (SPH) is available in this build\n", mode);
+        std::fprintf(stderr, "FSA_RUN_MODE=%s: this build has the SPH (WCSPH) and DFSPH steps\n", mode);
         std::exit(EXIT_FAILURE);
     }
     SetupSPH();

@@ -3,7 +3,7 @@
 // Step() per frame.
 //
 // The reference's Setup() always selects its IISPH step; which step runs here is chosen at run time:
-// environment variable FSA_RUN_MODE ("SPH", the default and the only step this build has), or a
+// environment variable FSA_RUN_MODE ("SPH" = WCSPH, the default, or "DFSPH"), or a
 // <RunMode> tag in the scene.  FSA_RESUME=<file> continues from a text checkpoint (key 'b').  Two more optional scene tags exist for the WCSPH step, which has no wall
 // response for TYPE_RIGID particles: <WallType> (particle type given to the boundary file's particles,
 // default 4 = TYPE_RIGID as LoadPO assigns), <WallRestDensity>, and <BoundaryMode> (0 verbatim
@@ -43,6 +43,7 @@ public:
     void SetupFluidScene();
     void ClearParticles();
     void SetupSPH();
+    void SetupDFSPH();
 
     void DumpSimulationDataText() override;
     void LoadSimulationDataText(const char *filepath);

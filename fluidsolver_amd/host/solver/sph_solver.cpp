@@ -91,6 +91,15 @@ void SPHSolver::SolveSPH() {
     check(fsa_advect(device), "Advect");
 }
 
+// SolveDFSPH, solver/sph_solver.cpp:108-120 (5 Jacobi rounds at most, threshold 1, no debug print)
+void SPHSolver::SolveDFSPH() {
+    check(fsa_compute_non_pressure_force(device), "computeNonPForce");
+    check(fsa_correct_density_error(device, 5, 1, nullptr, nullptr), "correctDensityError");
+    SortParticles();
+    check(fsa_compute_density_alpha(device), "computeDensityAlpha");
+    check(fsa_correct_divergence_error(device, 5, 1, nullptr, nullptr), "correctDivergenceError");
+}
+
 // Step, solver/sph_solver.cpp:129-142 and solver/MultiphaseSPHSolver.cpp:199-217
 void SPHSolver::Step() {
     if (numParticles > 0) {
@@ -98,8 +107,11 @@ void SPHSolver::Step() {
         case SPH:
             SolveSPH();
             break;
+        case DFSPH:
+            SolveDFSPH();
+            break;
         default:
-            std::fprintf(stderr, "run mode %d is not available in this build (only the WCSPH step is)\n", run_mode);
+            std::fprintf(stderr, "run mode %d is not available in this build (SPH and DFSPH are)\n", run_mode);
             std::exit(EXIT_FAILURE);
         }
     }

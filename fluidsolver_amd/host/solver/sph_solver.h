@@ -71,6 +71,7 @@ public:
 
     void SortParticles();
     void SolveSPH();
+    void SolveDFSPH();
 
     int AddDefaultParticle();
 

@@ -84,6 +84,7 @@ typedef struct fsa_params {
      * ghost layers included; slab_nz = 0 means the whole grid. */
     int slab_z0;
     int slab_nz;
+    double kpoly6; /* DFSPH density kernel constant (solver/MultiphaseSPHSolver.cpp:464) */
 } fsa_params;
 
 typedef struct fsa_solver fsa_solver;
@@ -171,12 +172,43 @@ int fsa_readback_pos_color(fsa_solver *s, void *pos3, void *color4, int *n);
  * gridCellEnd (num_cells ints; gridCellEnd is only meaningful where
  * gridCellStart != 0xffffffff, as in the reference); cellStartDense
  * (num_cells + 1 ints, exclusive prefix of the per-cell counts); orderKey (n 64-bit ints, slab
- * solvers only).
+ * solvers only); DF_factor pstiff error (n reals, DFSPH).
  * `bytes` must be the exact size.  Both synchronise.
  */
 int fsa_get_buffer(fsa_solver *s, const char *name, void *dst, size_t bytes);
-/* settable: pos vel force v_star mass density pressure restDensity type */
+/* settable: pos vel force v_star mass density pressure restDensity type DF_factor pstiff error */
 int fsa_set_buffer(fsa_solver *s, const char *name, const void *src, size_t bytes);
+
+/* ---- single-phase DFSPH step ------------------------------------------
+ *
+ * The other step of the reference's SPHSolver (solver/sph_solver.cpp:100-120), one entry per
+ * launcher of solver/sph_solver.cu:119-256.  Extra named buffers for fsa_get_buffer /
+ * fsa_set_buffer: DF_factor, pstiff, error (n reals each).  All need a sorted state except the two
+ * integration kernels.  Not available in slab solvers (v_star does not travel with the records).
+ */
+/* computeDensityAlpha: poly6 density and the DFSPH factor */
+int fsa_compute_density_alpha(fsa_solver *s);
+/* computeNonPForce: viscosity + wall penalty + gravity -> v_star */
+int fsa_compute_non_pressure_force(fsa_solver *s);
+/* the kernels the two correction loops launch: solveDensityStiff, solveDivergenceStiff, applyPStiff,
+ * updatePosition, UpdateVelocities (solver/sph_kernel_impl.cuh:818-1018) */
+int fsa_solve_density_stiff(fsa_solver *s);
+int fsa_solve_divergence_stiff(fsa_solver *s);
+int fsa_apply_pstiff(fsa_solver *s);
+int fsa_update_position(fsa_solver *s);
+int fsa_update_velocities(fsa_solver *s);
+/* correctDensityError / correctDivergenceError (solver/sph_solver.cu:144-256): Jacobi rounds until the
+ * maximum of error[] drops below ethres or maxiter rounds are done, then updatePosition /
+ * UpdateVelocities.  The maximum is reduced on the device (the reference copies error[] to the host
+ * every round); one 4- or 8-byte read-back per round remains, so both synchronise.  *iterations = rounds
+ * of applyPStiff done, *last_error = last maximum; either pointer may be NULL. */
+int fsa_correct_density_error(fsa_solver *s, int maxiter, double ethres, int *iterations, double *last_error);
+int fsa_correct_divergence_error(fsa_solver *s, int maxiter, double ethres, int *iterations, double *last_error);
+/* SetupDFSPH after the scene is uploaded (solver/sph_solver.cpp:102-106): sort + computeDensityAlpha */
+int fsa_setup_dfsph(fsa_solver *s);
+/* nsteps x SPHSolver::SolveDFSPH (solver/sph_solver.cpp:108-120, 5 rounds, threshold 1) without the
+ * host read-back of positions */
+int fsa_step_dfsph(fsa_solver *s, int nsteps);
 
 /* ---- measurement ------------------------------------------------------ */
 #define FSA_KERNEL_NAME_MAX 32

@@ -21,7 +21,7 @@ _VEC3 = ("pos", "vel", "normal", "force", "v_star",
          "sortedPos", "sortedVel", "sortedNormal", "sortedV_star")
 _VEC4 = ("color", "sortedColor")
 _REAL1 = ("mass", "density", "pressure", "restDensity",
-          "sortedMass", "sortedRestDensity", "sorted_pressure")
+          "sortedMass", "sortedRestDensity", "sorted_pressure", "DF_factor", "pstiff", "error")
 _INT1 = ("type", "group", "uniqueId", "indexTable", "sortedType", "sortedGroup",
          "sortedUniqueId", "particleHash", "particleIndex")
 _CELL = ("gridCellStart", "gridCellEnd")
@@ -35,6 +35,7 @@ _STATE_FIELDS = (
     "sortedMass", "sortedRestDensity", "sorted_pressure",
     "sortedType", "sortedGroup", "sortedUniqueId",
     "particleHash", "particleIndex", "gridCellStart", "gridCellEnd",
+    "DF_factor", "pstiff", "error",
 )
 
 
@@ -52,7 +53,7 @@ def _make_types(real):
             ("gravity", real * 3), ("dt", real), ("viscosity", real), ("spacing", real),
             ("smoothradius", real), ("kspikydiff", real), ("kernel_cubic", real),
             ("kernel_cubic_gradient", real), ("pressureK", real), ("boundary_visc", real),
-            ("acceleration_limit", real), ("boundary_mode", C.c_int),
+            ("acceleration_limit", real), ("boundary_mode", C.c_int), ("kpoly6", real),
         ]
 
     class State(C.Structure):
@@ -87,6 +88,12 @@ class Oracle:
         self._fn("sort_particle", None, [S])
         self._fn("copy_sorted_to_primary", None, [S])
         self._fn("solve_sph", None, [P, S, C.c_int])
+        for name in ("compute_density_alpha", "compute_non_pressure_force", "solve_density_stiff",
+                     "solve_divergence_stiff", "apply_pstiff", "update_position", "update_velocities"):
+            self._fn(name, None, [P, S])
+        for name in ("correct_density_error", "correct_divergence_error"):
+            self._fn(name, C.c_int, [P, S, C.c_int, self.real, C.POINTER(self.real)])
+        self._fn("solve_dfsph", None, [P, S, C.c_int])
 
     def _fn(self, name, restype, argtypes):
         f = getattr(self.lib, self.prefix + name)
@@ -184,3 +191,24 @@ class OracleState:
     def advect(self, p): self.orc._advect(C.byref(p), self._s)
     def rigid_particle_volume(self, p): self.orc._rigid_particle_volume(C.byref(p), self._s)
     def solve_sph(self, p, nsteps=1): self.orc._solve_sph(C.byref(p), self._s, int(nsteps))
+
+    # DFSPH ------------------------------------------------------------
+    def compute_density_alpha(self, p): self.orc._compute_density_alpha(C.byref(p), self._s)
+    def compute_non_pressure_force(self, p): self.orc._compute_non_pressure_force(C.byref(p), self._s)
+    def solve_density_stiff(self, p): self.orc._solve_density_stiff(C.byref(p), self._s)
+    def solve_divergence_stiff(self, p): self.orc._solve_divergence_stiff(C.byref(p), self._s)
+    def apply_pstiff(self, p): self.orc._apply_pstiff(C.byref(p), self._s)
+    def update_position(self, p): self.orc._update_position(C.byref(p), self._s)
+    def update_velocities(self, p): self.orc._update_velocities(C.byref(p), self._s)
+
+    def correct_density_error(self, p, maxiter=5, ethres=1.0):
+        e = self.orc.real()
+        it = self.orc._correct_density_error(C.byref(p), self._s, int(maxiter), ethres, C.byref(e))
+        return it, e.value
+
+    def correct_divergence_error(self, p, maxiter=5, ethres=1.0):
+        e = self.orc.real()
+        it = self.orc._correct_divergence_error(C.byref(p), self._s, int(maxiter), ethres, C.byref(e))
+        return it, e.value
+
+    def solve_dfsph(self, p, nsteps=1): self.orc._solve_dfsph(C.byref(p), self._s, int(nsteps))

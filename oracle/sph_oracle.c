@@ -65,6 +65,7 @@ state_t *ORC_NAME(create)(int n, int num_cells) {
     A1(sortedMass); A1(sortedRestDensity); A1(sorted_pressure);
     AI(sortedType); AI(sortedGroup); AI(sortedUniqueId);
     AI(particleHash); AI(particleIndex);
+    A1(DF_factor); A1(pstiff); A1(error);
 #undef A3
 #undef A4
 #undef A1
@@ -83,6 +84,7 @@ void ORC_NAME(destroy)(state_t *s) {
     free(s->sortedColor); free(s->sortedMass); free(s->sortedRestDensity); free(s->sorted_pressure);
     free(s->sortedType); free(s->sortedGroup); free(s->sortedUniqueId);
     free(s->particleHash); free(s->particleIndex); free(s->gridCellStart); free(s->gridCellEnd);
+    free(s->DF_factor); free(s->pstiff); free(s->error);
     free(s);
 }
 
@@ -105,6 +107,7 @@ void ORC_NAME(derive_params)(params_t *p, R spacing, R smoothratio, const R vmin
     p->kspikydiff = (R)(-45.0f / (3.141592 * (double)R_POW(sr, (R)6.0))); /* :466 */
     p->kernel_cubic = (R)(1 / 3.141593 / pow((double)(sr / 2), 3.0));     /* :468 */
     p->kernel_cubic_gradient = (R)(1.5 / (double)3.141593f / pow((double)(sr / 2), 4.0)); /* :469 */
+    p->kpoly6 = (R)(315.0f / (64.0f * 3.141592 * (double)R_POW(sr, (R)9.0)));             /* :464 */
 }
 
 /* ------------------------------------------------------------------ */
@@ -533,5 +536,327 @@ void ORC_NAME(solve_sph)(const params_t *p, state_t *s, int nsteps) {
         ORC_NAME(compute_pressure)(p, s);
         ORC_NAME(compute_force)(p, s);
         ORC_NAME(advect)(p, s);
+    }
+}
+
+/* ================================================================== */
+/* Single-phase DFSPH step.                                            */
+/* Kernels solver/sph_kernel_impl.cuh:582-1018, launchers               */
+/* solver/sph_solver.cu:119-256, step SPHSolver::SolveDFSPH             */
+/* solver/sph_solver.cpp:108-120.  All of it is float arithmetic except */
+/* where a double literal promotes (noted).                             */
+/* ================================================================== */
+
+/* Cell lookup shared by the DFSPH cell functions: false for a cell outside the grid or empty. */
+static inline int cell_range(const params_t *p, const state_t *s, int cx, int cy, int cz, unsigned *start,
+                             unsigned *end) {
+    unsigned gridHash = calc_grid_hash(p, cx, cy, cz);
+    if (gridHash == ORC_GRID_UNDEF) return 0;
+    *start = (unsigned)s->gridCellStart[gridHash];
+    if (*start == 0xffffffffu) return 0;
+    *end = (unsigned)s->gridCellEnd[gridHash];
+    return 1;
+}
+
+#define FOR_27_CELLS(g, ...)                                    \
+    for (int z = -1; z <= 1; z++)                               \
+        for (int y = -1; y <= 1; y++)                           \
+            for (int x = -1; x <= 1; x++) {                     \
+                unsigned startIndex, endIndex;                  \
+                if (!cell_range(p, s, (g)[0] + x, (g)[1] + y, (g)[2] + z, &startIndex, &endIndex)) continue; \
+                for (unsigned j = startIndex; j < endIndex; j++) __VA_ARGS__ \
+            }
+
+/* DensityAlphaCell :582-624 + computeDensityAlpha_kernel :626-660: poly6 density and the DFSPH factor */
+void ORC_NAME(compute_density_alpha)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R density = 0, mwij = 0, m3[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            if (j == (unsigned)index) continue;
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            R d = R_SQRT(d2);
+            R c2 = sr2 - d2;
+            R c = sr - d;
+            R nablaw = p->kspikydiff * c * c / d;
+            if (s->type[j] == ORC_TYPE_FLUID) {
+                density += c2 * c2 * c2 * s->mass[j];
+                R ax = xx * nablaw * s->mass[j], ay = xy * nablaw * s->mass[j], az = xz * nablaw * s->mass[j];
+                mwij += ax * ax + ay * ay + az * az;
+                m3[0] += ax;
+                m3[1] += ay;
+                m3[2] += az;
+            }
+        })
+        density += sr2 * sr2 * sr2 * s->mass[index];
+        density *= p->kpoly6;
+        s->density[index] = density;
+        R denom = m3[0] * m3[0] + m3[1] * m3[1] + m3[2] * m3[2] + mwij;
+        if ((double)denom < 0.000001) denom = (R)0.000001; /* clamp for stability, :656-657 */
+        s->DF_factor[index] = s->density[index] / denom;
+    }
+}
+
+/* computeNPFCell :663-742 + computeNPF_kernel :744-773: viscosity, wall penalty, gravity -> v_star */
+void ORC_NAME(compute_non_pressure_force)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        R *vs = s->v_star + 3 * (size_t)index;
+        if (s->type[index] != ORC_TYPE_FLUID) {
+            vs[0] = vs[1] = vs[2] = 0;
+            continue;
+        }
+        const R *pos = s->pos + 3 * (size_t)index;
+        const R *veli = s->vel + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R force[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            const R *velj = s->vel + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            R d = R_SQRT(d2);
+            if (j != (unsigned)index && s->type[j] == ORC_TYPE_FLUID) {
+                if (d2 >= sr2) continue;
+                R c = sr - d;
+                R nablaw = p->kspikydiff * c * c / d;
+                /* :703-704, `0.01 * sr2` is a double */
+                R vc = (R)((double)(nablaw * d2) / ((double)d2 + 0.01 * (double)sr2) * (double)s->mass[j] /
+                           (double)s->density[j] * 2 * (double)p->viscosity);
+                force[0] += (veli[0] - velj[0]) * vc;
+                force[1] += (veli[1] - velj[1]) * vc;
+                force[2] += (veli[2] - velj[2]) * vc;
+            }
+            if (s->type[j] == ORC_TYPE_BOUNDARY) { /* :708-739, the text of ForceCell's branch */
+                R B = 1;
+                R q = d / sr;
+                if ((double)q < 0.66666)
+                    B = (R)((double)B * 0.66666);
+                else if (q < 1)
+                    B = (R)((double)B * ((double)(2 * q) - 1.5 * (double)q * (double)q));
+                else if (q < 2)
+                    B = (R)((double)B * (0.5 * (double)(2 - q) * (double)(2 - q)));
+                else
+                    B = 0;
+                B = (R)((double)B * (0.02 * 88.5 * 88.5 / (double)d));
+                R magnitude = s->mass[j] / (s->mass[index] + s->mass[j]) * B;
+                force[0] += xx * magnitude;
+                force[1] += xy * magnitude;
+                force[2] += xz * magnitude;
+                R vx = veli[0] - velj[0], vy = veli[1] - velj[1], vz = veli[2] - velj[2];
+                R xv = vx * xx + vy * xy + vz * xz;
+                if (xv < 0) {
+                    R c = sr - d;
+                    R nablaw = p->kspikydiff * c * c / d;
+                    R visc = (R)((double)(2 * p->boundary_visc * p->smoothradius) * 88.5 / 2000);
+                    R pi = (R)((double)(-visc * xv) / ((double)d2 + 0.01 * (double)sr2));
+                    force[0] += xx * pi * nablaw * s->mass[j] * (R)(-1);
+                    force[1] += xy * pi * nablaw * s->mass[j] * (R)(-1);
+                    force[2] += xz * pi * nablaw * s->mass[j] * (R)(-1);
+                }
+            }
+        })
+        force[0] += (R)0;
+        force[1] += (R)-9.8; /* :770 */
+        force[2] += (R)0;
+        vs[0] = veli[0] + force[0] * p->dt;
+        vs[1] = veli[1] + force[1] * p->dt;
+        vs[2] = veli[2] + force[2] * p->dt;
+    }
+}
+
+/* sum over fluid neighbours of dot(v*_i - v*_j, grad W_ij m_j) (DensityChangeCell :775-813,
+ * PredictDensityCell :846-887); `scale_dt` multiplies every term by dt as the latter does */
+static inline R density_change(const params_t *p, const state_t *s, int index, R start, int scale_dt) {
+    const R sr = p->smoothradius, sr2 = sr * sr;
+    const R *pos = s->pos + 3 * (size_t)index;
+    const R *vsi = s->v_star + 3 * (size_t)index;
+    int g[3];
+    calc_grid_pos(p, pos, g);
+    R acc = start;
+    FOR_27_CELLS(g, {
+        if (j == (unsigned)index) continue;
+        const R *pos2 = s->pos + 3 * (size_t)j;
+        const R *vsj = s->v_star + 3 * (size_t)j;
+        R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+        R vx = vsi[0] - vsj[0], vy = vsi[1] - vsj[1], vz = vsi[2] - vsj[2];
+        R d2 = xx * xx + xy * xy + xz * xz;
+        if (d2 >= sr2) continue;
+        R d = R_SQRT(d2);
+        R c = sr - d;
+        R nablaw = p->kspikydiff * c * c / d;
+        if (s->type[j] == ORC_TYPE_FLUID) {
+            R nx = xx * nablaw * s->mass[j], ny = xy * nablaw * s->mass[j], nz = xz * nablaw * s->mass[j];
+            R dot = vx * nx + vy * ny + vz * nz;
+            if (scale_dt)
+                acc += dot * p->dt;
+            else
+                acc += dot;
+        }
+    })
+    return acc;
+}
+
+/* solveDivergenceStiff :818-842 */
+void ORC_NAME(solve_divergence_stiff)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] != ORC_TYPE_FLUID) {
+            s->error[index] = 0;
+            s->pstiff[index] = 0;
+            continue;
+        }
+        R densChange = density_change(p, s, index, 0, 0);
+        if (densChange < 0) densChange = 0;
+        s->error[index] = densChange / s->restDensity[index];
+        s->pstiff[index] = densChange / p->dt * s->DF_factor[index];
+    }
+}
+
+/* solveDensityStiff :890-919 */
+void ORC_NAME(solve_density_stiff)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] != ORC_TYPE_FLUID) {
+            s->error[index] = 0;
+            s->pstiff[index] = 0;
+            continue;
+        }
+        R density = density_change(p, s, index, s->density[index], 1);
+        s->pstiff[index] = (density - s->restDensity[index]) * s->DF_factor[index] / p->dt / p->dt;
+        s->error[index] = density - s->restDensity[index];
+        if (s->pstiff[index] < 0) {
+            s->pstiff[index] = 0;
+            s->error[index] = 0;
+        }
+    }
+}
+
+/* applyPressureCell :921-961 + applyPStiff :963-984.  v_star is updated in place while neighbours
+ * read pos / pstiff / density only, so the order of the particles does not matter. */
+void ORC_NAME(apply_pstiff)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] != ORC_TYPE_FLUID) continue;
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R force[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            if (j == (unsigned)index || s->type[j] != ORC_TYPE_FLUID) continue;
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            /* KernelGradient_Spiky :24-30 */
+            R d = R_SQRT(xx * xx + xy * xy + xz * xz);
+            R c = sr - d;
+            R factor = p->kspikydiff * c * c / d;
+            R nx = xx * factor * s->mass[j], ny = xy * factor * s->mass[j], nz = xz * factor * s->mass[j];
+            R w = s->pstiff[index] / s->density[index] + s->pstiff[j] / s->density[j];
+            force[0] += nx * w;
+            force[1] += ny * w;
+            force[2] += nz * w;
+        })
+        R *vs = s->v_star + 3 * (size_t)index;
+        vs[0] += force[0] * p->dt * (R)(-1);
+        vs[1] += force[1] * p->dt * (R)(-1);
+        vs[2] += force[2] * p->dt * (R)(-1);
+    }
+}
+
+/* updatePosition :986-992 */
+void ORC_NAME(update_position)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        for (int a = 0; a < 3; a++) s->pos[3 * (size_t)index + a] += s->v_star[3 * (size_t)index + a] * p->dt;
+    }
+}
+
+/* UpdateVelocities :995-1018 */
+void ORC_NAME(update_velocities)(const params_t *p, state_t *s) {
+    const int n = s->n;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        R *v = s->vel + 3 * (size_t)index, *vs = s->v_star + 3 * (size_t)index;
+        R a[3] = {vs[0] - v[0], vs[1] - v[1], vs[2] - v[2]};
+        for (int k = 0; k < 3; k++) a[k] /= p->dt;
+        R magnitude = R_SQRT(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        if (magnitude > p->acceleration_limit)
+            for (int k = 0; k < 3; k++) a[k] = a[k] / magnitude * p->acceleration_limit;
+        for (int k = 0; k < 3; k++) {
+            a[k] = p->gravity[k] - a[k];
+            v[k] = vs[k];
+            vs[k] = a[k];
+        }
+    }
+}
+
+static R max_error(const state_t *s, R start) {
+    R e = start;
+    for (int i = 0; i < s->n; i++) e = s->error[i] > e ? s->error[i] : e;
+    return e;
+}
+
+/* correctDensityError, solver/sph_solver.cu:144-210 (the maximum starts from -9999) */
+int ORC_NAME(correct_density_error)(const params_t *p, state_t *s, int maxiter, R ethres, R *last_error) {
+    int iter = 0;
+    R error = 0;
+    while (iter < maxiter) {
+        ORC_NAME(solve_density_stiff)(p, s);
+        error = max_error(s, (R)-9999);
+        if (error < ethres) break;
+        ORC_NAME(apply_pstiff)(p, s);
+        iter++;
+    }
+    ORC_NAME(update_position)(p, s);
+    if (last_error) *last_error = error;
+    return iter;
+}
+
+/* correctDivergenceError, solver/sph_solver.cu:212-256 (one extra solve first; the maximum starts from 0) */
+int ORC_NAME(correct_divergence_error)(const params_t *p, state_t *s, int maxiter, R ethres, R *last_error) {
+    int iter = 0;
+    R error = 0;
+    ORC_NAME(solve_divergence_stiff)(p, s);
+    while (iter < maxiter) {
+        ORC_NAME(solve_divergence_stiff)(p, s);
+        error = max_error(s, 0);
+        if (error < ethres) break;
+        ORC_NAME(apply_pstiff)(p, s);
+        iter++;
+    }
+    ORC_NAME(update_velocities)(p, s);
+    if (last_error) *last_error = error;
+    return iter;
+}
+
+/* SPHSolver::SolveDFSPH, solver/sph_solver.cpp:108-120; the state must have been prepared as
+ * SetupDFSPH does (:102-106): sorted, with compute_density_alpha run once. */
+void ORC_NAME(solve_dfsph)(const params_t *p, state_t *s, int nsteps) {
+    for (int k = 0; k < nsteps; k++) {
+        ORC_NAME(compute_non_pressure_force)(p, s);
+        ORC_NAME(correct_density_error)(p, s, 5, 1, NULL);
+        ORC_NAME(sort_particles)(p, s);
+        ORC_NAME(compute_density_alpha)(p, s);
+        ORC_NAME(correct_divergence_error)(p, s, 5, 1, NULL);
     }
 }

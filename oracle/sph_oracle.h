@@ -76,6 +76,7 @@ typedef struct ORC_NAME(params) {
     orc_real boundary_visc;
     orc_real acceleration_limit;
     int boundary_mode;
+    orc_real kpoly6; /* DFSPH density kernel constant, MultiphaseSPHSolver.cpp:464 */
 } ORC_NAME(params);
 
 /* Hot-path subset of SimData_SPH (solver/sph_solver.cuh:79-190): tight AoS
@@ -92,6 +93,7 @@ typedef struct ORC_NAME(state) {
     orc_real *sortedMass, *sortedRestDensity, *sorted_pressure;
     int *sortedType, *sortedGroup, *sortedUniqueId;
     int *particleHash, *particleIndex, *gridCellStart, *gridCellEnd;
+    orc_real *DF_factor, *pstiff, *error; /* DFSPH, n each (solver/sph_solver.cuh:79-190) */
 } ORC_NAME(state);
 
 ORC_NAME(state) *ORC_NAME(create)(int n, int num_cells);
@@ -116,6 +118,22 @@ void ORC_NAME(advect)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
 void ORC_NAME(rigid_particle_volume)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
 /* SPHSolver::SolveSPH without the D2H copy, sph_solver.cpp:87-98 */
 void ORC_NAME(solve_sph)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int nsteps);
+
+/* ---- single-phase DFSPH step (solver/sph_kernel_impl.cuh:582-1018, sph_solver.cu:119-256) ---- */
+void ORC_NAME(compute_density_alpha)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(compute_non_pressure_force)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(solve_density_stiff)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(solve_divergence_stiff)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(apply_pstiff)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(update_position)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(update_velocities)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+/* both return the number of applyPStiff rounds done; *last_error = the last maximum of error[] */
+int ORC_NAME(correct_density_error)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int maxiter, orc_real ethres,
+                                    orc_real *last_error);
+int ORC_NAME(correct_divergence_error)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int maxiter,
+                                       orc_real ethres, orc_real *last_error);
+/* SPHSolver::SolveDFSPH without the D2H copy, sph_solver.cpp:108-120 */
+void ORC_NAME(solve_dfsph)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int nsteps);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,150 @@
+"""DFSPH step on the GPU, stage by stage through the C ABI, against the oracle from the same state:
+1e-5 relative in fp32, 1e-10 in fp64; integration kernels and the iteration counts exact."""
+import numpy as np
+import pytest
+
+from fluidsolver_amd import capi, scenes
+from util import gpu_solver, oracle_pair, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(name):
+    if name == "dam_walls":
+        return scenes.jittered(scenes.dam_break(14, 12, 10, tank_x_factor=2.0), seed=21, pos_jitter=0.2, vel_scale=1.0)
+    sc = scenes.dam_break(12, 12, 12, tank_x_factor=2.0)
+    sc = scenes.jittered(sc, seed=22, pos_jitter=0.05, vel_scale=0.2)
+    fl = sc["type"] == 0
+    pos = np.array(sc["pos"])
+    pos[fl] = (pos[fl] - pos[fl].min(0)) * np.float32(0.96) + pos[fl].min(0)  # compressed: the solvers have work
+    sc["pos"] = pos
+    return sc
+
+
+@pytest.fixture(params=[("dam_walls", "f32"), ("compressed", "f32"), ("compressed", "f64")],
+                ids=lambda p: f"{p[0]}-{p[1]}")
+def pair(request, orc32, orc64):
+    name, prec = request.param
+    sc = scene(name)
+    if prec == "f64":
+        sc = dict(sc)
+        for k in ("pos", "vel", "color", "normal", "mass", "restDensity"):
+            sc[k] = np.asarray(sc[k], np.float64)
+    orc = orc32 if prec == "f32" else orc64
+    p_o, st = oracle_pair(orc, sc)
+    p_g, s = gpu_solver(sc, precision=capi.PRECISION_F32 if prec == "f32" else capi.PRECISION_F64)
+    tol = 1e-5 if prec == "f32" else 1e-10
+    yield sc, p_o, st, s, tol
+    s.close()
+    st.close()
+
+
+def sync_inputs(s, st, names):
+    for k in names:
+        s.set(k, st[k])
+
+
+def test_dfsph_stages_from_the_same_state(pair):
+    sc, p, st, s, tol = pair
+    st.sort_particles(p)
+    s.sort_particles()
+    assert np.array_equal(s.get("uniqueId"), st["uniqueId"])
+    fluid = st["type"] == 0
+
+    st.compute_density_alpha(p)
+    s.compute_density_alpha()
+    assert rel_err(s.get("density"), st["density"]) <= tol
+    assert rel_err(s.get("DF_factor"), st["DF_factor"]) <= tol
+
+    sync_inputs(s, st, ("density", "DF_factor"))
+    st.compute_non_pressure_force(p)
+    s.compute_non_pressure_force()
+    vs_g, vs_o = s.get("v_star"), st["v_star"]
+    assert rel_err(vs_g, vs_o) <= tol
+    assert np.all(vs_g[~fluid] == 0)
+
+    sync_inputs(s, st, ("v_star",))
+    st.solve_density_stiff(p)
+    s.solve_density_stiff()
+    # error = predicted density - rest density: a difference of nearly equal numbers, so the scale of
+    # the comparison is the density itself
+    assert np.abs(s.get("error").astype(np.float64) - st["error"]).max() <= tol * float(st["density"].max())
+    assert rel_err(s.get("pstiff"), st["pstiff"]) <= 50 * tol
+    assert np.array_equal(s.get("pstiff") > 0, st["pstiff"] > 0) or rel_err(s.get("pstiff"), st["pstiff"]) <= tol
+
+    sync_inputs(s, st, ("pstiff", "error"))
+    st.apply_pstiff(p)
+    s.apply_pstiff()
+    assert rel_err(s.get("v_star"), st["v_star"]) <= tol
+
+    sync_inputs(s, st, ("v_star",))
+    st.solve_divergence_stiff(p)
+    s.solve_divergence_stiff()
+    assert rel_err(s.get("error"), st["error"]) <= 20 * tol   # a sum with cancellation, scaled by 1 / rest density
+    assert rel_err(s.get("pstiff"), st["pstiff"]) <= 20 * tol
+
+    st.update_position(p)
+    s.update_position()
+    assert s.get("pos").tobytes() == st["pos"].tobytes()
+    st.update_velocities(p)
+    s.update_velocities()
+    assert s.get("vel").tobytes() == st["vel"].tobytes()
+    assert s.get("v_star").tobytes() == st["v_star"].tobytes()
+
+
+def test_correction_loops(pair):
+    sc, p, st, s, tol = pair
+    st.sort_particles(p)
+    s.sort_particles()
+    st.compute_density_alpha(p)
+    s.compute_density_alpha()
+    st.compute_non_pressure_force(p)
+    s.compute_non_pressure_force()
+    it_o, e_o = st.correct_density_error(p, 5, 1.0)
+    it_g, e_g = s.correct_density_error(5, 1.0)
+    assert it_g == it_o
+    assert abs(e_g - e_o) <= 1e-3 * max(abs(e_o), 1.0) if tol > 1e-8 else abs(e_g - e_o) <= 1e-8 * max(abs(e_o), 1.0)
+    scale = float(np.max(np.array(sc["params"]["vmax"]) - np.array(sc["params"]["vmin"])))
+    assert np.abs(s.get("pos").astype(np.float64) - st["pos"]).max() <= tol * scale
+    st.sort_particles(p)
+    s.sort_particles()
+    assert np.array_equal(s.get("uniqueId"), st["uniqueId"])
+    # v_star travels with the particles through the sort
+    assert rel_err(s.get("v_star"), st["v_star"]) <= 10 * tol
+    st.compute_density_alpha(p)
+    s.compute_density_alpha()
+    it_o, e_o = st.correct_divergence_error(p, 5, 1.0)
+    it_g, e_g = s.correct_divergence_error(5, 1.0)
+    assert it_g == it_o
+    assert rel_err(s.get("vel"), st["vel"]) <= 10 * tol
+
+
+def test_five_dfsph_steps(pair):
+    sc, p, st, s, tol = pair
+    st.sort_particles(p)
+    st.compute_density_alpha(p)
+    s.setup_dfsph()
+    st.solve_dfsph(p, 5)
+    s.step_dfsph(5)
+    a = s.get("pos")[np.argsort(s.get("uniqueId"))].astype(np.float64)
+    b = st["pos"][np.argsort(st["uniqueId"])].astype(np.float64)
+    scale = float(np.max(np.array(sc["params"]["vmax"]) - np.array(sc["params"]["vmin"])))
+    assert np.abs(a - b).max() <= 10 * tol * scale
+    assert np.isfinite(a).all()
+
+
+def test_v_star_is_reordered_with_the_particles_in_the_wcsph_step_too(orc32):
+    """rigid particles keep v_star = 0 (AdvectKernel skips them); the sort must carry that with them"""
+    sc = scenes.jittered(scenes.reference_scene(), seed=8, pos_jitter=0.1, vel_scale=0.2, fluid_only=True)
+    sc["params"] = dict(sc["params"], viscosity=scenes.WCSPH_VISCOSITY)
+    p_o, st = oracle_pair(orc32, sc)
+    p_g, s = gpu_solver(sc)
+    st.solve_sph(p_o, 3)
+    s.step(3)
+    assert np.array_equal(s.get("uniqueId"), st["uniqueId"])
+    assert s.get("v_star").tobytes() == st["v_star"].tobytes()
+    st.sort_particles(p_o)
+    s.sort_particles()
+    assert s.get("v_star").tobytes() == st["v_star"].tobytes()
+    s.close()
+    st.close()

@@ -189,3 +189,25 @@ def test_text_checkpoint_resume(tmp_path):
     kc = np.lexsort((pc[:, 2], pc[:, 1], pc[:, 0]))
     assert np.abs(np.sort(pa[:, 1]) - np.sort(pc[:, 1])).max() < 2e-5
     assert np.abs(pa[ka].mean(0) - pc[kc].mean(0)).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_headless_program_dfsph_mode(tmp_path):
+    from fluidsolver_amd import capi
+    frames = 6
+    final = tmp_path / "final.bin"
+    e = env_for(20)
+    e["FSA_RUN_MODE"] = "DFSPH"
+    subprocess.check_call([os.path.join(HOST, "bin", "particle_solver"), "--frames", str(frames), "--save-final",
+                           str(final)], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    pos, _ = read_final(final)
+    sc = scenes.dam_break(64, 32, 64)
+    p = capi.make_params(capi.PRECISION_F32, **sc["params"])
+    s = capi.Solver(p, len(sc["pos"]))
+    s.upload(sc)
+    s.setup_dfsph()
+    s.step_dfsph(frames)
+    want, _ = s.readback_pos_color()
+    assert pos.tobytes() == want.tobytes()
+    s.close()
