@@ -177,7 +177,9 @@ def main():
                                 "dam128k": "dam break 64x32x64 fluid particles"}[args.scene],
                    "particles_total": res["n"], "particles_counted": res["n_fluid"], "grid": res["gridres"],
                    "spinup_steps": args.spinup, "parallelism": f"z-slabs x{args.gpus}" if args.gpus > 1 else "1 GPU",
-                   "out_of_grid_particles": res["n_undef"]},
+                   "out_of_grid_particles": res["n_undef"],
+                   **{k: res[k] for k in ("comm_backend", "slab_cuts", "halo_layers", "max_local_particles",
+                                          "lost_particles", "records_sent_per_step") if k in res}},
         "roofline": roof, "kernels": kernels,
     }
     if args.gpus == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,7 @@ Layer ownership is fixed for a run: the cuts balance the initial per-layer parti
 from __future__ import annotations
 
 import os
+import sys
 import time
 
 import numpy as np
@@ -425,21 +426,42 @@ def bench_distributed(args, build_scene):
     device_index = local % ndev
     torch.cuda.set_device(device_index)
     device = torch.device("cuda", device_index)
-    # RCCL needs one GPU per rank; ranks sharing a card (rehearsal on a one-GPU box) go through gloo
-    backend = "nccl" if ndev >= world else "gloo"
+    # Control traffic (barriers, statistics) goes over a gloo group; the records go over RCCL whenever
+    # every rank has a GPU of its own, whatever the launcher did to device visibility.  Ranks sharing a
+    # card (rehearsal on a one-GPU box) stage the records through the host over gloo instead.
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    props = torch.cuda.get_device_properties(device_index)
+    ident = "|".join(str(getattr(props, a, "")) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if not ident.strip("|"):
+        ident = f"visible-index-{device_index}-of-{ndev}"
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    forced = os.environ.get("FSA_SLAB_BACKEND")  # "nccl" or "gloo" overrides the detection
+    use_nccl = (len(set(idents)) == world) if forced is None else forced == "nccl"
+    record_group = None
+    if use_nccl:
+        # the communicator is created here and now (device_id given); if any rank cannot, all ranks
+        # agree to stage the records through the host instead and the bench line says so
+        try:
+            record_group = dist.new_group(backend="nccl", device_id=device)
+            ok = 1
+        except Exception as exc:  # noqa: BLE001
+            print(f"rank {rank}: RCCL group creation failed ({exc}); records will be staged over gloo", file=sys.stderr)
+            ok = 0
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        if not all(oks):
+            record_group, use_nccl = None, False
+    backend = "nccl" if use_nccl else "gloo"
     sc = build_scene(args.scene, args.jitter)
     n, n_fluid = len(sc["pos"]), sc["n_fluid"]
-    transport = NeighbourTransport(rank, world, device)
+    transport = NeighbourTransport(rank, world, device, group=record_group)
     ss = SlabSolver(sc, rank, world, transport,
                     lambda P, held, cap: HipSlabBackend(P, held, cap, device_index, args.variant))
-    sync_dev = device if backend == "nccl" else torch.device("cpu")
+    sync_dev = torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize()
