@@ -208,7 +208,7 @@ def dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, wall_type=TYPE_BOUND
 
 
 def double_dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.005, obstacles=2) -> dict:
-    """BASELINE config 4 in small: two nx*ny*nz fluid blocks at the two x ends of the tank and `obstacles`
+    """Double dam break in small: two nx*ny*nz fluid blocks at the two x ends of the tank and `obstacles`
     box obstacles between them (filled TYPE_BOUNDARY lattices, the generator of BoundaryGenerator 'Cube',
     solver/ParticleGenerator.h:27-43), staggered in z so that the flow is not symmetric along z."""
     s = F32(spacing)

@@ -1,4 +1,4 @@
-"""BASELINE config 0, the plumbing case: a ball of ~33 K fluid particles (ball.raw scaled by 0.1) dropped
+"""The plumbing configuration: a ball of ~33 K fluid particles (ball.raw scaled by 0.1) dropped
 onto a floor plate in the shipped grid box, 1000 steps.  The reference ships no loader for ball.raw on the
 particle path, so the scene is this build's own construction (fluidsolver_amd.scenes.ball_drop)."""
 import numpy as np
