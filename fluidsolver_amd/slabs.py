@@ -108,34 +108,97 @@ class NeighbourTransport:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
+    @staticmethod
+    def _next_cap(count):
+        """message size both ends agree on for the next step: this step's count plus head room"""
+        return count + max(count // 8, 1024)
+
     def exchange(self, send, recv_bufs, record_bytes):
         """send = {peer: (uint8 tensor, count)}; recv_bufs = {peer: uint8 tensor}; returns {peer: count}.
-        Received records are in recv_bufs[peer][:count * record_bytes] when this returns (for device
-        buffers: stream-ordered on the current stream)."""
+
+        Every buffer starts with one header slot (a record's size) followed by the records, so the records
+        received from `peer` are recv_bufs[peer][record_bytes : (1 + count) * record_bytes] when this
+        returns (device buffers: stream-ordered on the current stream).
+
+        The first exchange with a peer sends the count ahead in a message of its own.  After that a
+        message has the size both ends derived from the previous count (`_next_cap`), its header slot
+        carries the actual count, and only if that count does not fit is the rest sent in a second
+        message: one round trip and one host synchronisation per step instead of two."""
         torch = self.torch
+        rb = record_bytes
         peers = sorted(send)
-        out_cnt = {p: torch.tensor([send[p][1]], dtype=torch.int64, device=self.comm_device) for p in peers}
-        in_cnt = {p: torch.zeros(1, dtype=torch.int64, device=self.comm_device) for p in peers}
-        self._batch([(p, out_cnt[p]) for p in peers], [(p, in_cnt[p]) for p in peers])
-        counts = {p: int(in_cnt[p].item()) for p in peers}
+        if not hasattr(self, "cap_out"):
+            self.cap_out, self.cap_in = {}, {}
+        counts = {}
+        first = [p for p in peers if p not in self.cap_out]
+        later = [p for p in peers if p in self.cap_out]
+
+        def stage_out(t):
+            return t.cpu() if self.staged else t
+
+        def write_header(buf, count):
+            buf[:8].copy_(torch.tensor([count], dtype=torch.int64).view(torch.uint8), non_blocking=True)
+
+        def check_room(p, records):
+            if (records + 1) * rb > recv_bufs[p].numel():
+                raise RuntimeError(f"rank {self.rank}: {records} records from rank {p} exceed the receive buffer")
+
+        # ---- peers seen for the first time: count, then payload --------------------------------
+        if first:
+            out_cnt = {p: torch.tensor([send[p][1]], dtype=torch.int64, device=self.comm_device) for p in first}
+            in_cnt = {p: torch.zeros(1, dtype=torch.int64, device=self.comm_device) for p in first}
+            self._batch([(p, out_cnt[p]) for p in first], [(p, in_cnt[p]) for p in first])
+            for p in first:
+                counts[p] = int(in_cnt[p].item())
+                check_room(p, counts[p])
+        # ---- one message per direction ----------------------------------------------------------
         sends, recvs, staged_in = [], [], {}
         for p in peers:
-            nb = send[p][1] * record_bytes
-            if nb:
-                t = send[p][0][:nb]
-                sends.append((p, t.cpu() if self.staged else t))
-            nb = counts[p] * record_bytes
-            if nb > recv_bufs[p].numel():
-                raise RuntimeError(f"rank {self.rank}: {counts[p]} records from rank {p} exceed the receive buffer")
-            if nb:
+            buf, cnt = send[p]
+            if p in first:
+                n_out, n_in = cnt, counts[p]          # exact sizes, header unused
+            else:
+                n_out, n_in = self.cap_out[p], self.cap_in[p]
+                write_header(buf, cnt)
+                check_room(p, n_in)
+            if p in later or n_out:
+                sends.append((p, stage_out(buf[:(1 + n_out) * rb])))
+            if p in later or n_in:
                 if self.staged:
-                    staged_in[p] = torch.empty(nb, dtype=torch.uint8)
+                    staged_in[p] = torch.empty((1 + n_in) * rb, dtype=torch.uint8)
                     recvs.append((p, staged_in[p]))
                 else:
-                    recvs.append((p, recv_bufs[p][:nb]))
+                    recvs.append((p, recv_bufs[p][:(1 + n_in) * rb]))
+        self._batch(sends, recvs)
+        # ---- headers, and the rare second message ------------------------------------------------
+        sends, recvs, tails = [], [], {}
+        for p in later:
+            src = staged_in[p] if self.staged else recv_bufs[p]
+            counts[p] = int(src[:8].view(torch.int64).item())
+            check_room(p, counts[p])
+            extra_in = counts[p] - self.cap_in[p]
+            if extra_in > 0:
+                if self.staged:
+                    tails[p] = torch.empty(extra_in * rb, dtype=torch.uint8)
+                    recvs.append((p, tails[p]))
+                else:
+                    lo = (1 + self.cap_in[p]) * rb
+                    recvs.append((p, recv_bufs[p][lo:lo + extra_in * rb]))
+            extra_out = send[p][1] - self.cap_out[p]
+            if extra_out > 0:
+                lo = (1 + self.cap_out[p]) * rb
+                sends.append((p, stage_out(send[p][0][lo:lo + extra_out * rb])))
         self._batch(sends, recvs)
         for p, t in staged_in.items():
-            recv_bufs[p][:t.numel()].copy_(t)
+            keep = (1 + min(counts[p], self.cap_in.get(p, counts[p]))) * rb
+            recv_bufs[p][:keep].copy_(t[:keep])
+        for p, t in tails.items():
+            lo = (1 + self.cap_in[p]) * rb
+            recv_bufs[p][lo:lo + t.numel()].copy_(t)
+        # never beyond the buffers (the two ends of a pair allocate theirs with the same size)
+        for p in peers:
+            self.cap_out[p] = min(self._next_cap(send[p][1]), send[p][0].numel() // rb - 1)
+            self.cap_in[p] = min(self._next_cap(counts[p]), recv_bufs[p].numel() // rb - 1)
         return counts
 
 
@@ -290,9 +353,12 @@ class SlabSolver:
         self.recuts = 0
 
     def _make_exchange_buffers(self):
-        self.send_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
-        self.recv_buf = {p: self.backend.make_buffer(self.record_cap) for p in self.peers}
-        self._null = self.backend.make_buffer(1)
+        # one header slot in front of the records (see NeighbourTransport.exchange)
+        self.send_buf = {p: self.backend.make_buffer(self.record_cap + 1) for p in self.peers}
+        self.recv_buf = {p: self.backend.make_buffer(self.record_cap + 1) for p in self.peers}
+        self._null = self.backend.make_buffer(2)
+        if self.transport is not None:
+            self.transport.cap_out, self.transport.cap_in = {}, {}  # sizes are agreed afresh
 
     def _record_layers(self, rec):
         """global cell layer of each record (rows of a (count, record_bytes) uint8 tensor), -1 outside"""
@@ -370,7 +436,8 @@ class SlabSolver:
         br = self.send_buf.get(r + 1, self._null)
         cl = self.record_cap if r - 1 in self.send_buf else 0
         cr = self.record_cap if r + 1 in self.send_buf else 0
-        kept, nl, nr, lost = self.backend.pack(self.own, self.held_layers, left, right, bl, cl, br, cr)
+        rb = self.backend.record_bytes
+        kept, nl, nr, lost = self.backend.pack(self.own, self.held_layers, left, right, bl[rb:], cl, br[rb:], cr)
         self.lost += lost
         send = {}
         if r - 1 in self.send_buf:
@@ -380,7 +447,7 @@ class SlabSolver:
         if send:
             got = self.transport.exchange(send, self.recv_buf, self.backend.record_bytes)
             for p in self.peers:  # fixed order: left neighbour first
-                self.backend.unpack(self.recv_buf[p], got[p])
+                self.backend.unpack(self.recv_buf[p][rb:], got[p])
         self.sent_records += nl + nr
 
     def step(self, nsteps=1):

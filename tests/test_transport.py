@@ -1,0 +1,25 @@
+"""Record transport between slab neighbours over gloo: the agreed-size messages with a count header,
+the second message when a count outgrows the agreed size, empty messages, both directions differing."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_slabs_cpu import free_port
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_with_jumping_counts(world):
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "transport_worker.py"), "--rank", str(r),
+                               "--world", str(world), "--port", str(port)]) for r in range(world)]
+    try:
+        codes = [p.wait(timeout=120) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world
