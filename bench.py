@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--spinup", type=int, default=int(os.environ.get("FSA_BENCH_SPINUP", 100)),
                     help="untimed steps before warm-up so that the dam has started to collapse")
     ap.add_argument("--scene", default=os.environ.get("FSA_BENCH_SCENE", "dam16m"),
-                    choices=["dam16m", "dam1m", "dam128k"])
+                    choices=["dam16m", "dam1m", "dam128k", "ddam64m"])
     ap.add_argument("--jitter", type=float, default=float(os.environ.get("FSA_BENCH_JITTER", 0.0)),
                     help="uniform position noise in units of the particle spacing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,13 +52,13 @@ def parse():
     return ap.parse_args()
 
 
-SCENES = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64)}
+SCENES = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64), "ddam64m": (320, 320, 320)}
 
 
 def build_scene(name, jitter=0.0):
     from fluidsolver_amd import scenes
     nx, ny, nz = SCENES[name]
-    sc = scenes.dam_break(nx, ny, nz)
+    sc = scenes.double_dam_break(nx, ny, nz) if name == "ddam64m" else scenes.dam_break(nx, ny, nz)
     if jitter > 0:
         n_fluid = sc["n_fluid"]
         sc = scenes.jittered(sc, seed=2024, pos_jitter=jitter, vel_scale=0.0, fluid_only=True)
@@ -174,7 +174,9 @@ def main():
         "config": {"workload": {"dam16m": "dam break, 256^3 = 16 777 216 fluid particles + one layer of wall "
                                           "particles, WCSPH fp32, shipped SceneId-2 parameters (viscosity 0.01)",
                                 "dam1m": "dam break 128x64x128 = 1 048 576 fluid particles",
-                                "dam128k": "dam break 64x32x64 fluid particles"}[args.scene],
+                                "dam128k": "dam break 64x32x64 fluid particles",
+                                "ddam64m": "double dam break, 2 x 320^3 = 65 536 000 fluid particles, box obstacles, "
+                                           "one layer of wall particles"}[args.scene],
                    "particles_total": res["n"], "particles_counted": res["n_fluid"], "grid": res["gridres"],
                    "spinup_steps": args.spinup, "parallelism": f"z-slabs x{args.gpus}" if args.gpus > 1 else "1 GPU",
                    "out_of_grid_particles": res["n_undef"],
