@@ -155,6 +155,7 @@ struct Staging {
 static void invalidate_order(Solver *s) {
     s->hash_valid = s->perm_valid = s->sorted_valid = false;
     s->index_table_valid = s->ref_cells_valid = false;
+    s->pd_valid = false;
 }
 
 }  // namespace fsa
@@ -472,6 +473,7 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
     s->cur = 1 - s->cur;
     s->sorted_valid = true;
     s->owned_from_sort = true;
+    s->pd_valid = false;
     s->hash_valid = false;  // hash[] described the previous order
     s->perm_valid = false;
     s->index_table_valid = false;
@@ -669,6 +671,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     };
     const int c = s->cur;
     FSA_HIP(hipStreamSynchronize(s->stream));
+    s->pd_valid = false;  // density, pressure, mass or viscosity may change under it
     auto plain = [&](void *ddst, size_t expect) -> int {
         TRY(want(expect));
         if (bytes) FSA_HIP(hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice));

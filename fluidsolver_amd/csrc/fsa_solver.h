@@ -83,6 +83,8 @@ struct Solver {
     bool index_table_valid = false;
     bool count_valid = false;   // cellStart[num_cells] holds the in-grid count of the last sort
     bool ref_cells_valid = false;
+    bool pd_valid = false;  // pd[] matches density / pressure / mass of the current arrays ...
+    bool pd_fast = false;   // ... in the fast flavour's layout
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)

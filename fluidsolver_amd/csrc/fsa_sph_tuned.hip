@@ -274,7 +274,8 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
                                                            const int *__restrict__ cellStart,
                                                            const int *__restrict__ sortedHash,
                                                            float *__restrict__ density,
-                                                           float *__restrict__ pressure, int ablate) {
+                                                           float *__restrict__ pressure,
+                                                           float2 *__restrict__ pd, int ablate) {
     using Shared = RowShared<BS, ROWCAP, false>;
     __shared__ Shared sh;
     __shared__ float queue[Q * BS];
@@ -384,6 +385,8 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
         float pr = P.pressureK * (r_pow(dens / rd_i, 7.0f) - 1);
         if (pr < 0) pr = 0;
         pressure[index] = pr;
+        // the per-particle terms of the force pass (what force_prep_kernel computes), while they are at hand
+        if (pd) pd[index] = make_float2(pr / dens / dens, FAST ? mass_i / dens * 2.0f * P.viscosity : dens);
     }
 }
 
@@ -633,15 +636,22 @@ int launch_density_tuned(Solver *s) {
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
     const int ablate = (g_ablate & 255) | (xcd_run_log() << 8);
     float *out0 = (float *)(g_out0 ? g_out0 : s->b.density), *out1 = (float *)(g_out1 ? g_out1 : s->b.pressure);
+    float2 *pd_out = g_out0 ? nullptr : (float2 *)s->b.pd;  // not in timing experiments
     if (s->variant == 2)
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, true>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
-                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, ablate);
+                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, pd_out,
+                           ablate);
     else
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, false>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
-                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, ablate);
+                           (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, pd_out,
+                           ablate);
     FSA_HIP(hipGetLastError());
+    if (pd_out) {
+        s->pd_valid = true;
+        s->pd_fast = s->variant == 2;
+    }
     return FSA_OK;
 }
 
@@ -649,7 +659,7 @@ int launch_force_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
     const int c = s->cur;
     const bool fast = s->variant == 2;
-    {
+    if (!(s->pd_valid && s->pd_fast == fast)) {
         ScopedTimer t(s, "force_prep");
         const dim3 g((s->n + kBlock - 1) / kBlock), b(kBlock);
         if (fast)
