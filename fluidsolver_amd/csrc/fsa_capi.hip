@@ -106,7 +106,7 @@ static void free_all(Solver *s) {
     Buffers &b = s->b;
     void *ptrs[] = {b.posType[0], b.posType[1], b.velMass[0], b.velMass[1], b.restDensity[0], b.restDensity[1],
                     b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.v_star_alt, b.DF_factor, b.pstiff,
-                    b.error, b.reduce_tmp, b.pd, b.hash, b.slot,
+                    b.error, b.reduce_tmp, b.aux4, b.pd, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
@@ -269,6 +269,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.pstiff, N * R, true);
     ALLOC(b.error, N * R, true);
     ALLOC(b.reduce_tmp, 2048 * sizeof(double), true);
+    ALLOC(b.aux4, N * 4 * R, true);
     ALLOC(b.pd, N * 2 * R, true);
     ALLOC(b.hash, N * sizeof(int), true);
     ALLOC(b.slot, N * sizeof(int), true);

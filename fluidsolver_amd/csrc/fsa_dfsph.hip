@@ -10,241 +10,426 @@
 // literals promote a float expression).
 #include <algorithm>
 
+#include <type_traits>
+
 #include "fsa_pair.h"
 #include "fsa_solver.h"
+#include "fsa_tile.h"
 
 namespace fsa {
 
-// Visits every particle j of the 27 cells around particle `index` in the reference's order.
-template <typename T, typename F>
-__device__ __forceinline__ void for_neighbours(const DevParams<T> &P, const Vec4<T> &pi,
-                                               const int *__restrict__ cellStart, F &&body) {
-    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++) {
-            int start, end;
-            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
-            for (int j = start; j < end; j++) body(j);
-        }
-}
+// Every neighbour pass of the step is written once, as a policy: which particles it covers, what it
+// reads of a neighbour, the loop body of the reference's *Cell function (`pair`), and what it stores.
+// Two kernels run a policy: generic_pass_kernel (one thread per particle, neighbours straight from
+// global memory; any precision) and tuned_pass_kernel (fp32: the LDS row tiles and per-lane hit queues
+// of the WCSPH force pass).  Both call the same `pair` in the same neighbour order, so they give the
+// same bits.
+template <typename T> struct DfArrays {
+    const Vec4<T> *posType;
+    const Vec4<T> *velMass;
+    const T *restDensity;
+    const T *density;
+    const T *dfFactor;
+    const T *pstiffIn;
+    const Vec3<T> *vStarIn;
+    const Vec4<T> *aux4;  // {v_star, mass} per particle (tuned density-change passes)
+    const T *aux2;        // {pstiff / density, mass} pairs (tuned applyPStiff)
+    T *densityOut;
+    T *dfFactorOut;
+    T *errorOut;
+    T *pstiffOut;
+    Vec3<T> *vStarOut;
+};
 
-// DensityAlphaCell :582-624 + computeDensityAlpha_kernel :626-660
-template <typename T>
-__global__ __launch_bounds__(kBlock) void density_alpha_kernel(DevParams<T> P, int n,
-                                                               const Vec4<T> *__restrict__ posType,
-                                                               const Vec4<T> *__restrict__ velMass,
-                                                               const int *__restrict__ cellStart,
-                                                               T *__restrict__ density, T *__restrict__ dfFactor) {
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n) return;
-    const Vec4<T> pi = posType[index];
-    const T sr = P.sr, sr2 = sr * sr;
-    T dens = 0, mwij = 0, mx = 0, my = 0, mz = 0;
-    for_neighbours(P, pi, cellStart, [&](int j) {
-        if (j == index) return;
-        const Vec4<T> pj = posType[j];
-        const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-        const T d2 = xx * xx + xy * xy + xz * xz;
+// ---- DensityAlphaCell :582-624 + computeDensityAlpha_kernel :626-660 -------------------------------
+template <typename T> struct AlphaPolicy {
+    static constexpr bool kWalls = false;
+    struct Self { T dens, mwij, mx, my, mz, mass; };
+    struct Nb { T mass; };
+    static __device__ __forceinline__ bool wants(int) { return true; }
+    static __device__ __forceinline__ void skip(const DfArrays<T> &, int) {}
+    static __device__ __forceinline__ void init(const DfArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.dens = S.mwij = S.mx = S.my = S.mz = 0;
+        S.mass = A.velMass[index].w;
+    }
+    static __device__ __forceinline__ Nb load(const DfArrays<T> &A, int j) {
+        return Nb{reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
+    }
+    static __device__ __forceinline__ void pair(const DevParams<T> &P, Self &S, bool self, int tj, T xx, T xy, T xz,
+                                                T d2, const Vec4<T> &, const Nb &nb) {
+        if (self) return;
+        const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
         const T d = r_sqrt(d2);
         const T c2 = sr2 - d2;
         const T c = sr - d;
         const T nablaw = P.kspikydiff * c * c / d;
-        if (unpack_int(pj.w) == FSA_TYPE_FLUID) {
-            const T mj = velMass[j].w;
-            dens += c2 * c2 * c2 * mj;
-            const T ax = xx * nablaw * mj, ay = xy * nablaw * mj, az = xz * nablaw * mj;
-            mwij += ax * ax + ay * ay + az * az;
-            mx += ax;
-            my += ay;
-            mz += az;
+        if (tj == FSA_TYPE_FLUID) {
+            S.dens += c2 * c2 * c2 * nb.mass;
+            const T ax = xx * nablaw * nb.mass, ay = xy * nablaw * nb.mass, az = xz * nablaw * nb.mass;
+            S.mwij += ax * ax + ay * ay + az * az;
+            S.mx += ax;
+            S.my += ay;
+            S.mz += az;
         }
-    });
-    dens += sr2 * sr2 * sr2 * velMass[index].w;
-    dens *= P.kpoly6;
-    density[index] = dens;
-    T denom = mx * mx + my * my + mz * mz + mwij;
-    if ((double)denom < 0.000001) denom = (T)0.000001;  // clamp for stability, :656-657
-    dfFactor[index] = dens / denom;
-}
-
-// computeNPFCell :663-742 + computeNPF_kernel :744-773: viscosity, wall penalty, gravity -> v_star
-template <typename T>
-__global__ __launch_bounds__(kBlock) void non_pressure_force_kernel(DevParams<T> P, int n,
-                                                                    const Vec4<T> *__restrict__ posType,
-                                                                    const Vec4<T> *__restrict__ velMass,
-                                                                    const T *__restrict__ density,
-                                                                    const int *__restrict__ cellStart,
-                                                                    Vec3<T> *__restrict__ v_star) {
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n) return;
-    ForceSelf<T> S;
-    S.p = posType[index];
-    if (unpack_int(S.p.w) != FSA_TYPE_FLUID) {
-        v_star[index] = Vec3<T>{0, 0, 0};
-        return;
     }
-    S.v = velMass[index];
-    S.pterm = 0;
-    S.fx = S.fy = S.fz = 0;
-    const T sr = P.sr, sr2 = sr * sr;
-    for_neighbours(P, S.p, cellStart, [&](int j) {
-        const Vec4<T> pj = posType[j];
-        const int tj = unpack_int(pj.w);
-        const T xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
-        const T d2 = xx * xx + xy * xy + xz * xz;
-        if (j != index && tj == FSA_TYPE_FLUID) {
+    static __device__ __forceinline__ void finish(const DfArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        const T sr2 = P.sr * P.sr;
+        T dens = S.dens + sr2 * sr2 * sr2 * S.mass;
+        dens *= P.kpoly6;
+        A.densityOut[index] = dens;
+        T denom = S.mx * S.mx + S.my * S.my + S.mz * S.mz + S.mwij;
+        if ((double)denom < 0.000001) denom = (T)0.000001;  // clamp for stability, :656-657
+        A.dfFactorOut[index] = dens / denom;
+    }
+};
+
+// ---- computeNPFCell :663-742 + computeNPF_kernel :744-773 ------------------------------------------
+template <typename T> struct NpfPolicy {
+    static constexpr bool kWalls = true;
+    struct Self { ForceSelf<T> F; };
+    struct Nb { Vec4<T> v; T dens; };
+    static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
+    static __device__ __forceinline__ void skip(const DfArrays<T> &A, int index) {
+        A.vStarOut[index] = Vec3<T>{0, 0, 0};
+    }
+    static __device__ __forceinline__ void init(const DfArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.F.p = A.posType[index];
+        S.F.v = A.velMass[index];
+        S.F.pterm = 0;
+        S.F.fx = S.F.fy = S.F.fz = 0;
+    }
+    static __device__ __forceinline__ Nb load(const DfArrays<T> &A, int j) { return Nb{A.velMass[j], A.density[j]}; }
+    static __device__ __forceinline__ void pair(const DevParams<T> &P, Self &S, bool self, int tj, T xx, T xy, T xz,
+                                                T d2, const Vec4<T> &pj, const Nb &nb) {
+        const T sr = P.sr, sr2 = sr * sr;
+        if (!self && tj == FSA_TYPE_FLUID) {
             if (d2 >= sr2) return;
             const T d = r_sqrt(d2);
             const T c = sr - d;
             const T nablaw = P.kspikydiff * c * c / d;
-            const Vec4<T> vj = velMass[j];
-            const T vc = (T)((double)(nablaw * d2) / ((double)d2 + 0.01 * (double)sr2) * (double)vj.w /
-                             (double)density[j] * 2 * (double)P.viscosity);
-            S.fx += (S.v.x - vj.x) * vc;
-            S.fy += (S.v.y - vj.y) * vc;
-            S.fz += (S.v.z - vj.z) * vc;
+            // :703-704, `0.01 * sr2` is a double
+            const T vc = (T)((double)(nablaw * d2) / ((double)d2 + 0.01 * (double)sr2) * (double)nb.v.w /
+                             (double)nb.dens * 2 * (double)P.viscosity);
+            S.F.fx += (S.F.v.x - nb.v.x) * vc;
+            S.F.fy += (S.F.v.y - nb.v.y) * vc;
+            S.F.fz += (S.F.v.z - nb.v.z) * vc;
         }
         // the wall branch is ForceCell's, text for text; force_pair does nothing else for this type
-        if (tj == FSA_TYPE_BOUNDARY) force_pair(P, sr, sr2, S, j == index, pj, velMass[j], (T)0, (T)1);
-    });
-    S.fx += (T)0;
-    S.fy += (T)-9.8;  // :770
-    S.fz += (T)0;
-    Vec3<T> vs;
-    vs.x = S.v.x + S.fx * P.dt;
-    vs.y = S.v.y + S.fy * P.dt;
-    vs.z = S.v.z + S.fz * P.dt;
-    v_star[index] = vs;
-}
+        if (tj == FSA_TYPE_BOUNDARY) force_pair(P, sr, sr2, S.F, self, pj, nb.v, (T)0, (T)1);
+    }
+    static __device__ __forceinline__ void finish(const DfArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        S.F.fx += (T)0;
+        S.F.fy += (T)-9.8;  // :770
+        S.F.fz += (T)0;
+        Vec3<T> vs;
+        vs.x = S.F.v.x + S.F.fx * P.dt;
+        vs.y = S.F.v.y + S.F.fy * P.dt;
+        vs.z = S.F.v.z + S.F.fz * P.dt;
+        A.vStarOut[index] = vs;
+    }
+};
 
-// sum over fluid neighbours of dot(v*_i - v*_j, grad W_ij m_j): DensityChangeCell :775-813 and, with
-// every term times dt, PredictDensityCell :846-887
-template <typename T, bool TIMES_DT>
-__device__ __forceinline__ T density_change(const DevParams<T> &P, int index, const Vec4<T> &pi, T start,
-                                            const Vec4<T> *__restrict__ posType,
-                                            const Vec4<T> *__restrict__ velMass,
-                                            const Vec3<T> *__restrict__ v_star,
-                                            const int *__restrict__ cellStart) {
-    const T sr = P.sr, sr2 = sr * sr;
-    const Vec3<T> vi = v_star[index];
-    T acc = start;
-    for_neighbours(P, pi, cellStart, [&](int j) {
-        if (j == index) return;
-        const Vec4<T> pj = posType[j];
-        const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-        const T d2 = xx * xx + xy * xy + xz * xz;
+// ---- DensityChangeCell :775-813 / PredictDensityCell :846-887 and the two kernels around them -------
+// TIMES_DT = false: solveDivergenceStiff :818-842; true: solveDensityStiff :890-919
+template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
+    static constexpr bool kWalls = false;
+    struct Self { T acc; Vec3<T> vs; };
+    struct Nb { T vx, vy, vz, mass; };
+    static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
+    static __device__ __forceinline__ void skip(const DfArrays<T> &A, int index) {
+        A.errorOut[index] = 0;
+        A.pstiffOut[index] = 0;
+    }
+    static __device__ __forceinline__ void init(const DfArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.acc = TIMES_DT ? A.density[index] : (T)0;
+        S.vs = A.vStarIn[index];
+    }
+    static __device__ __forceinline__ Nb load(const DfArrays<T> &A, int j) {
+        if (PACKED) {
+            const Vec4<T> a = A.aux4[j];
+            return Nb{a.x, a.y, a.z, a.w};
+        }
+        const Vec3<T> v = A.vStarIn[j];
+        return Nb{v.x, v.y, v.z, reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
+    }
+    static __device__ __forceinline__ void pair(const DevParams<T> &P, Self &S, bool self, int tj, T xx, T xy, T xz,
+                                                T d2, const Vec4<T> &, const Nb &nb) {
+        if (self) return;
+        const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
         const T d = r_sqrt(d2);
         const T c = sr - d;
         const T nablaw = P.kspikydiff * c * c / d;
-        if (unpack_int(pj.w) == FSA_TYPE_FLUID) {
-            const Vec3<T> vj = v_star[j];
-            const T vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
-            const T mj = velMass[j].w;
-            const T nx = xx * nablaw * mj, ny = xy * nablaw * mj, nz = xz * nablaw * mj;
+        if (tj == FSA_TYPE_FLUID) {
+            const T vx = S.vs.x - nb.vx, vy = S.vs.y - nb.vy, vz = S.vs.z - nb.vz;
+            const T nx = xx * nablaw * nb.mass, ny = xy * nablaw * nb.mass, nz = xz * nablaw * nb.mass;
             const T dot = vx * nx + vy * ny + vz * nz;
-            acc += TIMES_DT ? dot * P.dt : dot;
+            S.acc += TIMES_DT ? dot * P.dt : dot;
         }
-    });
-    return acc;
-}
-
-// solveDivergenceStiff :818-842
-template <typename T>
-__global__ __launch_bounds__(kBlock) void divergence_stiff_kernel(DevParams<T> P, int n,
-                                                                  const Vec4<T> *__restrict__ posType,
-                                                                  const Vec4<T> *__restrict__ velMass,
-                                                                  const T *__restrict__ restDensity,
-                                                                  const Vec3<T> *__restrict__ v_star,
-                                                                  const T *__restrict__ dfFactor,
-                                                                  const int *__restrict__ cellStart,
-                                                                  T *__restrict__ error, T *__restrict__ pstiff) {
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n) return;
-    const Vec4<T> pi = posType[index];
-    if (unpack_int(pi.w) != FSA_TYPE_FLUID) {
-        error[index] = 0;
-        pstiff[index] = 0;
-        return;
     }
-    T densChange = density_change<T, false>(P, index, pi, (T)0, posType, velMass, v_star, cellStart);
-    if (densChange < 0) densChange = 0;
-    error[index] = densChange / restDensity[index];
-    pstiff[index] = densChange / P.dt * dfFactor[index];
-}
-
-// solveDensityStiff :890-919
-template <typename T>
-__global__ __launch_bounds__(kBlock) void density_stiff_kernel(DevParams<T> P, int n,
-                                                               const Vec4<T> *__restrict__ posType,
-                                                               const Vec4<T> *__restrict__ velMass,
-                                                               const T *__restrict__ restDensity,
-                                                               const Vec3<T> *__restrict__ v_star,
-                                                               const T *__restrict__ density,
-                                                               const T *__restrict__ dfFactor,
-                                                               const int *__restrict__ cellStart,
-                                                               T *__restrict__ error, T *__restrict__ pstiff) {
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n) return;
-    const Vec4<T> pi = posType[index];
-    if (unpack_int(pi.w) != FSA_TYPE_FLUID) {
-        error[index] = 0;
-        pstiff[index] = 0;
-        return;
+    static __device__ __forceinline__ void finish(const DfArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        const T rd = A.restDensity[index];
+        if (TIMES_DT) {
+            T ps = (S.acc - rd) * A.dfFactor[index] / P.dt / P.dt;
+            T err = S.acc - rd;
+            if (ps < 0) {
+                ps = 0;
+                err = 0;
+            }
+            A.pstiffOut[index] = ps;
+            A.errorOut[index] = err;
+        } else {
+            T densChange = S.acc;
+            if (densChange < 0) densChange = 0;
+            A.errorOut[index] = densChange / rd;
+            A.pstiffOut[index] = densChange / P.dt * A.dfFactor[index];
+        }
     }
-    const T dens = density_change<T, true>(P, index, pi, density[index], posType, velMass, v_star, cellStart);
-    const T rd = restDensity[index];
-    T ps = (dens - rd) * dfFactor[index] / P.dt / P.dt;
-    T err = dens - rd;
-    if (ps < 0) {
-        ps = 0;
-        err = 0;
-    }
-    pstiff[index] = ps;
-    error[index] = err;
-}
+};
 
-// applyPressureCell :921-961 + applyPStiff :963-984.  Neighbours are read through pos / pstiff /
-// density only, v_star is written for the particle itself: no ordering hazard between threads.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void apply_pstiff_kernel(DevParams<T> P, int n,
-                                                              const Vec4<T> *__restrict__ posType,
-                                                              const Vec4<T> *__restrict__ velMass,
-                                                              const T *__restrict__ density,
-                                                              const T *__restrict__ pstiff,
-                                                              const int *__restrict__ cellStart,
-                                                              Vec3<T> *__restrict__ v_star) {
-    const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n) return;
-    const Vec4<T> pi = posType[index];
-    if (unpack_int(pi.w) != FSA_TYPE_FLUID) return;
-    const T sr = P.sr, sr2 = sr * sr;
-    const T wi = pstiff[index] / density[index];
-    T fx = 0, fy = 0, fz = 0;
-    for_neighbours(P, pi, cellStart, [&](int j) {
-        if (j == index) return;
-        const Vec4<T> pj = posType[j];
-        if (unpack_int(pj.w) != FSA_TYPE_FLUID) return;
-        const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-        const T d2 = xx * xx + xy * xy + xz * xz;
+// ---- applyPressureCell :921-961 + applyPStiff :963-984 ---------------------------------------------
+// Neighbours are read through pos / pstiff / density only, v_star is written for the particle itself:
+// no ordering hazard between threads.
+template <typename T, bool PACKED> struct ApplyPolicy {
+    static constexpr bool kWalls = false;
+    struct Self { T wi, fx, fy, fz; };
+    struct Nb { T w, mass; };  // w = pstiff_j / density_j
+    static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
+    static __device__ __forceinline__ void skip(const DfArrays<T> &, int) {}
+    static __device__ __forceinline__ void init(const DfArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.wi = A.pstiffIn[index] / A.density[index];
+        S.fx = S.fy = S.fz = 0;
+    }
+    static __device__ __forceinline__ Nb load(const DfArrays<T> &A, int j) {
+        if (PACKED) return Nb{A.aux2[2 * (size_t)j], A.aux2[2 * (size_t)j + 1]};
+        return Nb{A.pstiffIn[j] / A.density[j], reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
+    }
+    static __device__ __forceinline__ void pair(const DevParams<T> &P, Self &S, bool self, int tj, T xx, T xy, T xz,
+                                                T d2, const Vec4<T> &, const Nb &nb) {
+        if (self || tj != FSA_TYPE_FLUID) return;
+        const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
         // KernelGradient_Spiky :24-30
         const T d = r_sqrt(xx * xx + xy * xy + xz * xz);
         const T c = sr - d;
         const T factor = P.kspikydiff * c * c / d;
-        const T mj = velMass[j].w;
-        const T nx = xx * factor * mj, ny = xy * factor * mj, nz = xz * factor * mj;
-        const T w = wi + pstiff[j] / density[j];
-        fx += nx * w;
-        fy += ny * w;
-        fz += nz * w;
-    });
-    Vec3<T> vs = v_star[index];
-    vs.x += fx * P.dt * (T)(-1);
-    vs.y += fy * P.dt * (T)(-1);
-    vs.z += fz * P.dt * (T)(-1);
-    v_star[index] = vs;
+        const T nx = xx * factor * nb.mass, ny = xy * factor * nb.mass, nz = xz * factor * nb.mass;
+        const T w = S.wi + nb.w;
+        S.fx += nx * w;
+        S.fy += ny * w;
+        S.fz += nz * w;
+    }
+    static __device__ __forceinline__ void finish(const DfArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        Vec3<T> vs = A.vStarIn[index];
+        vs.x += S.fx * P.dt * (T)(-1);
+        vs.y += S.fy * P.dt * (T)(-1);
+        vs.z += S.fz * P.dt * (T)(-1);
+        A.vStarOut[index] = vs;
+    }
+};
+
+// One particle against its 27 cells in the reference's order, neighbours from global memory.
+template <typename T, typename Policy>
+__device__ __forceinline__ void generic_walk(const DevParams<T> &P, const DfArrays<T> &A, int index,
+                                             const Vec4<T> &pi, const int *__restrict__ cellStart,
+                                             typename Policy::Self &S) {
+    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const Vec4<T> pj = A.posType[j];
+                const int tj = unpack_int(pj.w);
+                if (tj != FSA_TYPE_FLUID && !(Policy::kWalls && tj == FSA_TYPE_BOUNDARY)) continue;
+                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const T d2 = xx * xx + xy * xy + xz * xz;
+                Policy::pair(P, S, j == index, tj, xx, xy, xz, d2, pj, Policy::load(A, j));
+            }
+        }
+}
+
+template <typename T, typename Policy>
+__global__ __launch_bounds__(kBlock) void generic_pass_kernel(DevParams<T> P, int n, DfArrays<T> A,
+                                                              const int *__restrict__ cellStart) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    const Vec4<T> pi = A.posType[index];
+    if (!Policy::wants(unpack_int(pi.w))) {
+        Policy::skip(A, index);
+        return;
+    }
+    typename Policy::Self S;
+    Policy::init(A, P, index, S);
+    generic_walk<T, Policy>(P, A, index, pi, cellStart, S);
+    Policy::finish(A, P, index, S);
+}
+
+// The tiled flavour (fp32): row tiles in LDS, each lane culls its range of every row into a queue of
+// 16-bit (row, index) entries, the queue is drained in double-buffered batches of gathered neighbours.
+// Candidates enter the queue on a fused squared distance with a little slack; `pair` then applies the
+// reference's own tests, in queue (= reference) order.
+template <typename Policy, int BS, int ROWCAP, int Q>
+__global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int n, DfArrays<float> A,
+                                                        const int *__restrict__ cellStart,
+                                                        const int *__restrict__ sortedHash, int xcd_log) {
+    using Shared = RowShared<BS, ROWCAP, true>;
+    __shared__ Shared sh;
+    __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
+    const int tid = threadIdx.x;
+    const int b0 = xcd_block(xcd_log) * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int nb = min(BS, n - b0);
+    const int index = b0 + tid;
+    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool active = false;
+    if (index < n) {
+        pi = A.posType[index];
+        active = Policy::wants(unpack_int(pi.w));
+        if (!active) Policy::skip(A, index);
+    }
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
+    typename Policy::Self S;
+    if (active) Policy::init(A, P, index, S);
+    if (!staged) {
+        if (active) {
+            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+            Policy::finish(A, P, index, S);
+        }
+        return;
+    }
+    const float sr = P.sr, sr2c = sr * sr * 1.000002f;
+    const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
+    unsigned short *const q = queue + tid;
+    const int safe = index < n ? index : 0;
+    int cnt = 0;
+
+    struct Batch {
+        int j[kDrainBatch];
+        float4 pj[kDrainBatch];
+        typename Policy::Nb nb[kDrainBatch];
+    };
+    auto batch_load = [&](Batch &B, int s) {
+#pragma unroll
+        for (int u = 0; u < kDrainBatch; u++) {
+            const int e = q[(s + u) * BS];
+            B.j[u] = s + u < cnt ? sh.rowStartG[e >> 9] + (e & 511) : safe;
+        }
+#pragma unroll
+        for (int u = 0; u < kDrainBatch; u++) {
+            B.pj[u] = A.posType[B.j[u]];
+            B.nb[u] = Policy::load(A, B.j[u]);
+        }
+    };
+    auto batch_eval = [&](const Batch &B, int s) {
+#pragma unroll
+        for (int u = 0; u < kDrainBatch; u++)
+            if (s + u < cnt) {
+                const float xx = pi.x - B.pj[u].x, xy = pi.y - B.pj[u].y, xz = pi.z - B.pj[u].z;
+                const float d2 = xx * xx + xy * xy + xz * xz;
+                Policy::pair(P, S, B.j[u] == index, unpack_int(B.pj[u].w), xx, xy, xz, d2, B.pj[u], B.nb[u]);
+            }
+    };
+    auto drain = [&]() {
+        Batch B0, B1;
+        batch_load(B0, 0);
+        for (int s = 0; wave_any(s < cnt); s += 2 * kDrainBatch) {
+            batch_load(B1, s + kDrainBatch);
+            batch_eval(B0, s);
+            if (!wave_any(s + kDrainBatch < cnt)) break;
+            batch_load(B0, s + 2 * kDrainBatch);
+            batch_eval(B1, s + kDrainBatch);
+        }
+        cnt = 0;
+    };
+
+    float4 e0, e1;
+    int lj, le, nlj = 0, nle = 0;
+    row_fetch<BS, ROWCAP, false>(sh, 0, A.posType, e0, e1);
+    lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+    row_store<BS, ROWCAP, true>(sh, 0, e0, e1);
+    __syncthreads();
+    for (int r = 0; r < 9; r++) {
+        const int buf = r & 1;
+        if (r + 1 < 9) {
+            row_fetch<BS, ROWCAP, false>(sh, r + 1, A.posType, e0, e1);
+            lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+        }
+        const int tag = r << 9;
+        auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            float d2[kChunk];
+            group_d2<true>(sh.x[buf][g], sh.y[buf][g], sh.z[buf][g], pi.x, pi.y, pi.z, d2);
+            const int4 T4 = sh.t[buf][g];
+            const int tj[kChunk] = {T4.x, T4.y, T4.z, T4.w};
+            const int etag = tag | (g * kChunk);
+            if (!wave_any((T4.x | T4.y | T4.z | T4.w) != 0)) {
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    q[cnt * BS] = (unsigned short)(etag + u);  // a miss is overwritten by the next store
+                    cnt += (d2[u] < sr2c && (!MASKED || (u >= lo && u < hi))) ? 1 : 0;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    const bool mine = !MASKED || (u >= lo && u < hi);
+                    if (mine && ((tj[u] == FSA_TYPE_FLUID && d2[u] < sr2c) ||
+                                 (Policy::kWalls && tj[u] == FSA_TYPE_BOUNDARY))) {
+                        q[cnt * BS] = (unsigned short)(etag + u);
+                        cnt++;
+                    }
+                }
+            }
+        };
+        const bool has = lj < le;
+        int base = lj & ~(kChunk - 1);
+        if (wave_any(has)) {
+            cull_group(has ? base / kChunk : Shared::kPad, lj - base, le - base, std::true_type());
+            if (wave_any(cnt > Q - kChunk)) drain();
+        }
+        base = has ? base + kChunk : le;
+        while (wave_any(base + kChunk <= le)) {
+            const bool go = base + kChunk <= le;
+            cull_group(go ? base / kChunk : Shared::kPad, 0, kChunk, std::false_type());
+            base += go ? kChunk : 0;
+            if (wave_any(cnt > Q - kChunk)) drain();
+        }
+        if (wave_any(base < le)) {
+            const int rem = le - base;
+            cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
+            if (wave_any(cnt > Q - kChunk)) drain();
+        }
+        if (r + 1 < 9) {
+            row_store<BS, ROWCAP, true>(sh, buf ^ 1, e0, e1);
+            lj = nlj;
+            le = nle;
+            __syncthreads();
+        }
+    }
+    drain();
+    if (active) Policy::finish(A, P, index, S);
+}
+
+// per-particle records the tuned passes gather instead of two or three separate arrays
+__global__ __launch_bounds__(kBlock) void pack_vstar_mass_kernel(int n, const Vec3<float> *__restrict__ v_star,
+                                                                 const float4 *__restrict__ velMass,
+                                                                 float4 *__restrict__ aux4) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Vec3<float> v = v_star[i];
+    aux4[i] = make_float4(v.x, v.y, v.z, velMass[i].w);
+}
+__global__ __launch_bounds__(kBlock) void pack_pstiff_mass_kernel(int n, const float *__restrict__ pstiff,
+                                                                  const float *__restrict__ density,
+                                                                  const float4 *__restrict__ velMass,
+                                                                  float2 *__restrict__ aux2) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    aux2[i] = make_float2(pstiff[i] / density[i], velMass[i].w);
 }
 
 // updatePosition :986-992
@@ -333,50 +518,122 @@ static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlo
         FSA_HIP(hipGetLastError());                                                                               \
     } while (0)
 
+template <typename T> static DfArrays<T> arrays_of(Solver *s) {
+    const int c = s->cur;
+    DfArrays<T> A{};
+    A.posType = (const Vec4<T> *)s->b.posType[c];
+    A.velMass = (const Vec4<T> *)s->b.velMass[c];
+    A.restDensity = (const T *)s->b.restDensity[c];
+    A.density = (const T *)s->b.density;
+    A.dfFactor = (const T *)s->b.DF_factor;
+    A.pstiffIn = (const T *)s->b.pstiff;
+    A.vStarIn = (const Vec3<T> *)s->b.v_star;
+    A.aux4 = (const Vec4<T> *)s->b.aux4;
+    A.aux2 = (const T *)s->b.pd;
+    A.densityOut = (T *)s->b.density;
+    A.dfFactorOut = (T *)s->b.DF_factor;
+    A.errorOut = (T *)s->b.error;
+    A.pstiffOut = (T *)s->b.pstiff;
+    A.vStarOut = (Vec3<T> *)s->b.v_star;
+    return A;
+}
+
+constexpr int kQueueDf = 48;  // 16-bit slots, as in the WCSPH force pass
+
+static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F32 && s->variant >= 1; }
+
+// Policy<float> through the tiled kernel
+template <typename Policy> static int launch_tuned(Solver *s, const char *tag) {
+    ScopedTimer t(s, tag);
+    const int unit = kXcds << xcd_run_log();
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
+                       s->stream, s->pf, s->n, arrays_of<float>(s), s->b.cellStart, s->b.sortedHash, xcd_run_log());
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// Policy<T> through the one-thread-per-particle kernel, either precision
+#define DF_GENERIC(PolicyT, tag)                                                                           \
+    do {                                                                                                   \
+        ScopedTimer t(s, tag);                                                                             \
+        if (s->precision == FSA_PRECISION_F32) {                                                           \
+            using T = float;                                                                               \
+            hipLaunchKernelGGL((generic_pass_kernel<T, PolicyT>), dim3(blocks_for(s->n)), dim3(kBlock), 0, \
+                               s->stream, s->pf, s->n, arrays_of<T>(s), s->b.cellStart);                   \
+        } else {                                                                                           \
+            using T = double;                                                                              \
+            hipLaunchKernelGGL((generic_pass_kernel<T, PolicyT>), dim3(blocks_for(s->n)), dim3(kBlock), 0, \
+                               s->stream, s->pd, s->n, arrays_of<T>(s), s->b.cellStart);                   \
+        }                                                                                                  \
+        FSA_HIP(hipGetLastError());                                                                        \
+    } while (0)
+
+static int pack_vstar_mass(Solver *s) {
+    ScopedTimer t(s, "pack_vstar_mass");
+    hipLaunchKernelGGL(pack_vstar_mass_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                       (const Vec3<float> *)s->b.v_star, (const float4 *)s->b.velMass[s->cur], (float4 *)s->b.aux4);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
 int launch_density_alpha(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    ScopedTimer t(s, "density_alpha");
-    const int c = s->cur;
-    DF_DISPATCH(density_alpha_kernel, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
-                s->b.cellStart, (T *)s->b.density, (T *)s->b.DF_factor);
+    if (use_tiles(s)) return launch_tuned<AlphaPolicy<float>>(s, "density_alpha");
+    DF_GENERIC(AlphaPolicy<T>, "density_alpha");
     return FSA_OK;
 }
 
 int launch_non_pressure_force(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    ScopedTimer t(s, "non_pressure_force");
-    const int c = s->cur;
-    DF_DISPATCH(non_pressure_force_kernel, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
-                (const T *)s->b.density, s->b.cellStart, (Vec3<T> *)s->b.v_star);
+    if (use_tiles(s)) return launch_tuned<NpfPolicy<float>>(s, "non_pressure_force");
+    DF_GENERIC(NpfPolicy<T>, "non_pressure_force");
     return FSA_OK;
 }
 
 int launch_solve_density_stiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    ScopedTimer t(s, "density_stiff");
-    const int c = s->cur;
-    DF_DISPATCH(density_stiff_kernel, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
-                (const T *)s->b.restDensity[c], (const Vec3<T> *)s->b.v_star, (const T *)s->b.density,
-                (const T *)s->b.DF_factor, s->b.cellStart, (T *)s->b.error, (T *)s->b.pstiff);
+    if (use_tiles(s)) {
+        int rc = pack_vstar_mass(s);
+        if (rc) return rc;
+        return launch_tuned<StiffPolicy<float, true, true>>(s, "density_stiff");
+    }
+    // (these policy names carry commas, which a macro argument cannot: hence the alias macro)
+#define FSA_POLICY StiffPolicy<T, true, false>
+    DF_GENERIC(FSA_POLICY, "density_stiff");
+#undef FSA_POLICY
     return FSA_OK;
 }
 
 int launch_solve_divergence_stiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    ScopedTimer t(s, "divergence_stiff");
-    const int c = s->cur;
-    DF_DISPATCH(divergence_stiff_kernel, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
-                (const T *)s->b.restDensity[c], (const Vec3<T> *)s->b.v_star, (const T *)s->b.DF_factor,
-                s->b.cellStart, (T *)s->b.error, (T *)s->b.pstiff);
+    if (use_tiles(s)) {
+        int rc = pack_vstar_mass(s);
+        if (rc) return rc;
+        return launch_tuned<StiffPolicy<float, false, true>>(s, "divergence_stiff");
+    }
+#define FSA_POLICY StiffPolicy<T, false, false>
+    DF_GENERIC(FSA_POLICY, "divergence_stiff");
+#undef FSA_POLICY
     return FSA_OK;
 }
 
 int launch_apply_pstiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    ScopedTimer t(s, "apply_pstiff");
-    const int c = s->cur;
-    DF_DISPATCH(apply_pstiff_kernel, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
-                (const T *)s->b.density, (const T *)s->b.pstiff, s->b.cellStart, (Vec3<T> *)s->b.v_star);
+    if (use_tiles(s)) {
+        {
+            ScopedTimer t(s, "pack_pstiff_mass");
+            s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
+            hipLaunchKernelGGL(pack_pstiff_mass_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                               (const float *)s->b.pstiff, (const float *)s->b.density,
+                               (const float4 *)s->b.velMass[s->cur], (float2 *)s->b.pd);
+            FSA_HIP(hipGetLastError());
+        }
+        return launch_tuned<ApplyPolicy<float, true>>(s, "apply_pstiff");
+    }
+#define FSA_POLICY ApplyPolicy<T, false>
+    DF_GENERIC(FSA_POLICY, "apply_pstiff");
+#undef FSA_POLICY
     return FSA_OK;
 }
 

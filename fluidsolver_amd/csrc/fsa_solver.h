@@ -33,6 +33,7 @@ struct Buffers {
     void *pstiff = nullptr;
     void *error = nullptr;
     void *reduce_tmp = nullptr;  // block maxima of error[]
+    void *aux4 = nullptr;        // {v_star, mass} per particle for the tiled DFSPH passes
     void *pd = nullptr;      // {pressure / density^2, density} pairs for the tuned force pass
     // neighbour search
     int *hash = nullptr;         // cell of particle i (device order before the sort)

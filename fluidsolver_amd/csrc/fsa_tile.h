@@ -1,0 +1,148 @@
+// Shared machinery of the LDS-tiled neighbour passes (density, force, DFSPH): the row tile in LDS, the
+// per-block row table, row fetch / store, the per-lane cell range, and the workgroup -> XCD mapping.
+// See fsa_sph_tuned.hip for the description of the scheme.
+#pragma once
+
+#include <cstdlib>
+
+#include "fsa_pair.h"
+
+namespace fsa {
+
+constexpr int kTunedBS = 256;
+constexpr int kRowCap = 384;  // typical row: 34 cells x 8 particles = 272
+constexpr int kChunk = 4;  // candidates fetched per lane and loop trip
+constexpr int kDrainBatch = 2;  // force drain: neighbours per batch (two batches in flight)
+constexpr float kFar = 3.0e18f;
+
+// Row tile in LDS, coordinates apart so that one 16-byte read yields four candidates.  The group
+// after the last full one (index ROWCAP / 4) only ever holds far-away padding: lanes that have nothing
+// left to do read it.
+template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
+    static constexpr int kGroups = (ROWCAP + kChunk) / kChunk;
+    static constexpr int kPad = ROWCAP / kChunk;
+    float4 x[2][kGroups], y[2][kGroups], z[2][kGroups];
+    int4 t[WITH_TYPE ? 2 : 1][WITH_TYPE ? kGroups : 1];
+    int rowStartG[9];  // first particle (global index) of each row
+    int rowLen[9];
+    int staged;
+};
+
+// Block-uniform set-up.  Returns false when this block must take the per-particle path.
+template <int ROWCAP, typename Shared>
+__device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, int nb,
+                                           const int *__restrict__ cellStart,
+                                           const int *__restrict__ sortedHash, Shared &sh, unsigned hlo,
+                                           unsigned hhi) {
+    const int tid = threadIdx.x;
+    const int C = P.num_cells;
+    const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
+    if (tid < 9) {
+        int s = 0, len = -1;
+        if (grid_ok) {
+            const int dz = tid / 3 - 1, dy = tid % 3 - 1;
+            const long long off = (long long)dy * P.gres[0] * P.nz + (long long)dz * P.gres[0];
+            long long a = (long long)hlo + off - 1, b = (long long)hhi + off + 2;
+            a = a < 0 ? 0 : (a > C ? C : a);
+            b = b < 0 ? 0 : (b > C ? C : b);
+            s = cellStart[a];
+            len = cellStart[b] - s;
+        }
+        sh.rowStartG[tid] = s;
+        sh.rowLen[tid] = len;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bool ok = grid_ok;
+        for (int r = 0; r < 9; r++)
+            if (sh.rowLen[r] < 0 || sh.rowLen[r] > ROWCAP) ok = false;
+        sh.staged = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return sh.staged != 0;
+}
+
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+// Row r of the tile: every thread fetches its (at most two) entries into registers ...
+// FLUID_ONLY: particles of any other type are moved far away, so that the cull needs no type test.
+template <int BS, int ROWCAP, bool FLUID_ONLY, typename Shared>
+__device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 *__restrict__ posType, float4 &e0,
+                                          float4 &e1) {
+    static_assert(ROWCAP + kChunk <= 2 * BS, "two entries per thread must cover a row");
+    const int tid = threadIdx.x;
+    const int s = sh.rowStartG[r], len = sh.rowLen[r];
+    // entries past the row's end read some valid address and are then replaced by far-away padding
+    const int last = len > 0 ? len - 1 : 0;
+    e0 = posType[s + min(tid, last)];
+    e1 = posType[s + min(tid + BS, last)];
+    const float4 far = make_float4(kFar, kFar, kFar, 0.0f);
+    if (tid >= len || (FLUID_ONLY && unpack_int(e0.w) != FSA_TYPE_FLUID)) e0 = far;
+    if (tid + BS >= len || (FLUID_ONLY && unpack_int(e1.w) != FSA_TYPE_FLUID)) e1 = far;
+}
+// ... and stores them later, after the previous row has been examined.
+template <int BS, int ROWCAP, bool WITH_TYPE, typename Shared>
+__device__ __forceinline__ void row_store(Shared &sh, int buf, const float4 &e0, const float4 &e1) {
+    const int tid = threadIdx.x;
+    float *const x = reinterpret_cast<float *>(sh.x[buf]);
+    float *const y = reinterpret_cast<float *>(sh.y[buf]);
+    float *const z = reinterpret_cast<float *>(sh.z[buf]);
+    x[tid] = e0.x;
+    y[tid] = e0.y;
+    z[tid] = e0.z;
+    if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[tid] = unpack_int(e0.w);
+    if (tid + BS < ROWCAP + kChunk) {
+        x[tid + BS] = e1.x;
+        y[tid + BS] = e1.y;
+        z[tid + BS] = e1.z;
+        if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[tid + BS] = unpack_int(e1.w);
+    }
+}
+
+// The lane's index range in row r, relative to the row's first particle (two loads of the cell table).
+template <typename Shared>
+__device__ __forceinline__ void lane_range(const DevParams<float> &P, const Shared &sh, const RowWalk<float> &walk,
+                                           bool active, int r, const int *__restrict__ cellStart, int &lj, int &le) {
+    lj = 0;
+    le = 0;
+    if (active) {
+        const int c = walk.row_cell(P, r % 3 - 1, r / 3 - 1);
+        if (c >= 0) {
+            const int s = sh.rowStartG[r];
+            lj = cellStart[c] - s;
+            le = cellStart[c + (walk.xhi - walk.xlo) + 1] - s;
+        }
+    }
+}
+
+// Squared distances of the four candidates of group g to the point (px, py, pz).
+template <bool FAST>
+__device__ __forceinline__ void group_d2(const float4 &X, const float4 &Y, const float4 &Z, float px, float py,
+                                         float pz, float (&d2)[kChunk]) {
+    const float xs[kChunk] = {X.x, X.y, X.z, X.w}, ys[kChunk] = {Y.x, Y.y, Y.z, Y.w}, zs[kChunk] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+    for (int u = 0; u < kChunk; u++) {
+        const float xx = px - xs[u], xy = py - ys[u], xz = pz - zs[u];
+        d2[u] = FAST ? __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx)) : xx * xx + xy * xy + xz * xz;
+    }
+}
+
+// Workgroups are handed to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and every XCD has
+// its own L2.  Blocks of consecutive sorted particles share most of their neighbour rows, so runs of
+// 64 consecutive blocks go to one XCD instead of every eighth block (measured: 5 % on the force pass;
+// one contiguous eighth of the range per XCD is slower, the eighths differ too much in cost).
+constexpr int kXcds = 8;
+inline int xcd_run_log() {  // FSA_XCD_RUN_LOG overrides the run length (log2) for experiments
+    static const int v = [] {
+        const char *e = getenv("FSA_XCD_RUN_LOG");
+        const int x = e ? atoi(e) : 6;
+        return x < 0 ? 0 : (x > 12 ? 12 : x);
+    }();
+    return v;
+}
+__device__ __forceinline__ int xcd_block(int run_log) {
+    const int x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+    return ((k >> run_log) * kXcds + x) * (1 << run_log) + (k & ((1 << run_log) - 1));
+}
+
+}  // namespace fsa
