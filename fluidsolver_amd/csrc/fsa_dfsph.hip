@@ -43,7 +43,8 @@ template <typename T> struct DfArrays {
 
 // ---- DensityAlphaCell :582-624 + computeDensityAlpha_kernel :626-660 -------------------------------
 template <typename T> struct AlphaPolicy {
-    static constexpr bool kWalls = false;
+    // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
+    static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T dens, mwij, mx, my, mz, mass; };
     struct Nb { T mass; };
     static __device__ __forceinline__ bool wants(int) { return true; }
@@ -86,7 +87,9 @@ template <typename T> struct AlphaPolicy {
 
 // ---- computeNPFCell :663-742 + computeNPF_kernel :744-773 ------------------------------------------
 template <typename T> struct NpfPolicy {
-    static constexpr bool kWalls = true;
+    static __device__ __forceinline__ int reach(int tj) {
+        return tj == FSA_TYPE_FLUID ? 1 : (tj == FSA_TYPE_BOUNDARY ? 2 : 0);
+    }
     struct Self { ForceSelf<T> F; };
     struct Nb { Vec4<T> v; T dens; };
     static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
@@ -133,7 +136,8 @@ template <typename T> struct NpfPolicy {
 // ---- DensityChangeCell :775-813 / PredictDensityCell :846-887 and the two kernels around them -------
 // TIMES_DT = false: solveDivergenceStiff :818-842; true: solveDensityStiff :890-919
 template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
-    static constexpr bool kWalls = false;
+    // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
+    static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T acc; Vec3<T> vs; };
     struct Nb { T vx, vy, vz, mass; };
     static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
@@ -192,7 +196,8 @@ template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
 // Neighbours are read through pos / pstiff / density only, v_star is written for the particle itself:
 // no ordering hazard between threads.
 template <typename T, bool PACKED> struct ApplyPolicy {
-    static constexpr bool kWalls = false;
+    // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
+    static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T wi, fx, fy, fz; };
     struct Nb { T w, mass; };  // w = pstiff_j / density_j
     static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
@@ -229,6 +234,40 @@ template <typename T, bool PACKED> struct ApplyPolicy {
     }
 };
 
+// ---- DensityCell :203-244 + ComputePressureKernel :246-266, TYPE_RIGID term included ---------------
+// (the dedicated WCSPH density kernel of fsa_sph_tuned.hip leaves that term out and is used for scenes
+// without rigid particles)
+template <typename T> struct DensityRigidPolicy {
+    static __device__ __forceinline__ int reach(int tj) {
+        return (tj == FSA_TYPE_FLUID || tj == FSA_TYPE_RIGID) ? 1 : 0;
+    }
+    struct Self { T dens, mass, rd; };
+    struct Nb { T rd; };
+    static __device__ __forceinline__ bool wants(int) { return true; }
+    static __device__ __forceinline__ void skip(const DfArrays<T> &, int) {}
+    static __device__ __forceinline__ void init(const DfArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.dens = 0;
+        S.mass = A.velMass[index].w;
+        S.rd = A.restDensity[index];
+    }
+    static __device__ __forceinline__ Nb load(const DfArrays<T> &A, int j) { return Nb{A.restDensity[j]}; }
+    static __device__ __forceinline__ void pair(const DevParams<T> &P, Self &S, bool, int tj, T xx, T xy, T xz, T d2,
+                                                const Vec4<T> &, const Nb &nb) {
+        const T sr2 = P.sr * P.sr;
+        if (d2 >= sr2) return;
+        const T h = (T)((double)P.sr * 0.5);
+        const T wij = kernel_cubic(P, h, xx, xy, xz);
+        if (tj == FSA_TYPE_FLUID) S.dens += S.mass * wij;
+        if (tj == FSA_TYPE_RIGID) S.dens += S.rd * nb.rd * wij;
+    }
+    static __device__ __forceinline__ void finish(const DfArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        A.densityOut[index] = S.dens;
+        T pr = P.pressureK * (r_pow(S.dens / S.rd, (T)7) - 1);
+        if (pr < 0) pr = 0;
+        A.pstiffOut[index] = pr;  // the launcher points this at the pressure array
+    }
+};
+
 // One particle against its 27 cells in the reference's order, neighbours from global memory.
 template <typename T, typename Policy>
 __device__ __forceinline__ void generic_walk(const DevParams<T> &P, const DfArrays<T> &A, int index,
@@ -242,7 +281,7 @@ __device__ __forceinline__ void generic_walk(const DevParams<T> &P, const DfArra
             for (int j = start; j < end; j++) {
                 const Vec4<T> pj = A.posType[j];
                 const int tj = unpack_int(pj.w);
-                if (tj != FSA_TYPE_FLUID && !(Policy::kWalls && tj == FSA_TYPE_BOUNDARY)) continue;
+                if (Policy::reach(tj) == 0) continue;
                 const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
                 const T d2 = xx * xx + xy * xy + xz * xz;
                 Policy::pair(P, S, j == index, tj, xx, xy, xz, d2, pj, Policy::load(A, j));
@@ -377,8 +416,8 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
                     const bool mine = !MASKED || (u >= lo && u < hi);
-                    if (mine && ((tj[u] == FSA_TYPE_FLUID && d2[u] < sr2c) ||
-                                 (Policy::kWalls && tj[u] == FSA_TYPE_BOUNDARY))) {
+                    const int reach = Policy::reach(tj[u]);
+                    if (mine && ((reach == 1 && d2[u] < sr2c) || reach == 2)) {
                         q[cnt * BS] = (unsigned short)(etag + u);
                         cnt++;
                     }
@@ -573,6 +612,20 @@ static int pack_vstar_mass(Solver *s) {
     ScopedTimer t(s, "pack_vstar_mass");
     hipLaunchKernelGGL(pack_vstar_mass_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
                        (const Vec3<float> *)s->b.v_star, (const float4 *)s->b.velMass[s->cur], (float4 *)s->b.aux4);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// WCSPH density for scenes with TYPE_RIGID particles, tiled (fp32, variant >= 1)
+int launch_density_rigid_tuned(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "density");
+    DfArrays<float> A = arrays_of<float>(s);
+    A.pstiffOut = (float *)s->b.pressure;
+    const int unit = kXcds << xcd_run_log();
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    hipLaunchKernelGGL((tuned_pass_kernel<DensityRigidPolicy<float>, kTunedBS, kRowCap, kQueueDf>), dim3(nb),
+                       dim3(kTunedBS), 0, s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, xcd_run_log());
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

@@ -139,6 +139,7 @@ int launch_update_position(Solver *s);
 int launch_update_velocities(Solver *s);
 int launch_max_error(Solver *s, double start, double *out);  // synchronises
 int launch_density_tuned(Solver *s);
+int launch_density_rigid_tuned(Solver *s);
 int launch_force_tuned(Solver *s);
 int debug_time_pass(Solver *s, int which, int ablate, int reps);
 int slab_record_bytes(const Solver *s);

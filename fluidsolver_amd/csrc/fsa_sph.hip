@@ -245,8 +245,10 @@ static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlo
 
 int launch_density(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    // the tuned density kernel has no TYPE_RIGID term
+    // the dedicated tuned density kernel has no TYPE_RIGID term; scenes with rigid particles take the
+    // tiled pass with the exact arithmetic (slab runs keep the generic kernel: it knows the halo rules)
     if (s->precision == FSA_PRECISION_F32 && s->variant >= 1 && !s->has_rigid) return launch_density_tuned(s);
+    if (s->precision == FSA_PRECISION_F32 && s->variant >= 1 && !s->slab) return launch_density_rigid_tuned(s);
     ScopedTimer t(s, "density");
     const int c = s->cur;
     FSA_DISPATCH(density_kernel, s->n, P, s->n, (const Vec4<T> *)s->b.posType[c], (const Vec4<T> *)s->b.velMass[c],
