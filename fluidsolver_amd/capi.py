@@ -34,6 +34,9 @@ EXPORTS = (
     "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
     "fsa_solve_divergence_stiff", "fsa_apply_pstiff", "fsa_update_position", "fsa_update_velocities",
     "fsa_correct_density_error", "fsa_correct_divergence_error", "fsa_setup_dfsph", "fsa_step_dfsph",
+    "fsa_non_pressure_force_multiphase", "fsa_iisph_factor", "fsa_iisph_predict_density", "fsa_iisph_calc_dijpjl",
+    "fsa_iisph_calc_new_pressure", "fsa_iisph_solve_pressure", "fsa_iisph_calc_pressure_force", "fsa_iisph_update",
+    "fsa_setup_iisph", "fsa_step_iisph",
 )
 
 
@@ -50,6 +53,7 @@ class Params(C.Structure):
         ("kspikydiff", C.c_double), ("kernel_cubic", C.c_double), ("kernel_cubic_gradient", C.c_double),
         ("pressureK", C.c_double), ("boundary_visc", C.c_double), ("acceleration_limit", C.c_double),
         ("boundary_mode", C.c_int), ("slab_z0", C.c_int), ("slab_nz", C.c_int), ("kpoly6", C.c_double),
+        ("surface_tension", C.c_double), ("boundary_friction", C.c_double),
     ]
 
     @property
@@ -132,6 +136,10 @@ def load() -> C.CDLL:
         "fsa_update_velocities": [H], "fsa_setup_dfsph": [H], "fsa_step_dfsph": [H, C.c_int],
         "fsa_correct_density_error": [H, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)],
         "fsa_correct_divergence_error": [H, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)],
+        "fsa_non_pressure_force_multiphase": [H], "fsa_iisph_factor": [H], "fsa_iisph_predict_density": [H],
+        "fsa_iisph_calc_dijpjl": [H], "fsa_iisph_calc_new_pressure": [H], "fsa_iisph_calc_pressure_force": [H],
+        "fsa_iisph_update": [H], "fsa_setup_iisph": [H], "fsa_step_iisph": [H, C.c_int],
+        "fsa_iisph_solve_pressure": [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)],
     }
     for name, args in protos.items():
         f = getattr(lib, name)
@@ -148,7 +156,8 @@ def check(rc: int) -> None:
 
 def make_params(precision=PRECISION_F32, *, spacing, smoothratio, vmin, vmax, gravity=(0.0, -10.0, 0.0),
                 dt=0.0004, viscosity=0.05, pressureK=1119.0, boundary_visc=0.0, acceleration_limit=0.0,
-                boundary_mode=BOUNDARY_VERBATIM, slab_z0=0, slab_nz=0, **_ignored) -> Params:
+                boundary_mode=BOUNDARY_VERBATIM, slab_z0=0, slab_nz=0, surface_tension=0.0,
+                boundary_friction=0.0, **_ignored) -> Params:
     """Parameter block as MultiphaseSPHSolver::ParseParam/LoadParam fill it."""
     lib = load()
     p = Params()
@@ -163,6 +172,8 @@ def make_params(precision=PRECISION_F32, *, spacing, smoothratio, vmin, vmax, gr
     p.boundary_mode = boundary_mode
     p.slab_z0 = slab_z0
     p.slab_nz = slab_nz
+    p.surface_tension = surface_tension
+    p.boundary_friction = boundary_friction
     return p
 
 
@@ -179,6 +190,7 @@ BUFFERS = {
     "gridCellStart": ("c", 0), "gridCellEnd": ("c", 0), "cellStartDense": ("c", 1),
     "orderKey": ("l", 1),
     "DF_factor": ("r", 1), "pstiff": ("r", 1), "error": ("r", 1),
+    "dii": ("r", 3), "dijpjl": ("r", 3), "pressureForce": ("r", 3), "aii": ("r", 1), "density_star": ("r", 1),
 }
 
 
@@ -314,6 +326,22 @@ class Solver:
     def correct_divergence_error(self, maxiter=5, ethres=1.0):
         it, e = C.c_int(), C.c_double()
         check(self.lib.fsa_correct_divergence_error(self._h, int(maxiter), float(ethres), C.byref(it), C.byref(e)))
+        return it.value, e.value
+
+    # -- IISPH ------------------------------------------------------------------------
+    def non_pressure_force_multiphase(self): check(self.lib.fsa_non_pressure_force_multiphase(self._h))
+    def iisph_factor(self): check(self.lib.fsa_iisph_factor(self._h))
+    def iisph_predict_density(self): check(self.lib.fsa_iisph_predict_density(self._h))
+    def iisph_calc_dijpjl(self): check(self.lib.fsa_iisph_calc_dijpjl(self._h))
+    def iisph_calc_new_pressure(self): check(self.lib.fsa_iisph_calc_new_pressure(self._h))
+    def iisph_calc_pressure_force(self): check(self.lib.fsa_iisph_calc_pressure_force(self._h))
+    def iisph_update(self): check(self.lib.fsa_iisph_update(self._h))
+    def setup_iisph(self): check(self.lib.fsa_setup_iisph(self._h))
+    def step_iisph(self, nsteps: int = 1): check(self.lib.fsa_step_iisph(self._h, int(nsteps)))
+
+    def iisph_solve_pressure(self, maxiter=10):
+        it, e = C.c_int(), C.c_double()
+        check(self.lib.fsa_iisph_solve_pressure(self._h, int(maxiter), C.byref(it), C.byref(e)))
         return it.value, e.value
 
     # -- z-slab decomposition --------------------------------------------------------

@@ -70,7 +70,10 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.sr = (T)h.smoothradius;
     d.kspikydiff = (T)h.kspikydiff;
     d.kernel_cubic = (T)h.kernel_cubic;
+    d.kernel_cubic_gradient = (T)h.kernel_cubic_gradient;
     d.kpoly6 = (T)h.kpoly6;
+    d.surface_tension = (T)h.surface_tension;
+    d.boundary_friction = (T)h.boundary_friction;
     d.pressureK = (T)h.pressureK;
     d.boundary_visc = (T)h.boundary_visc;
     d.accel_limit = (T)h.acceleration_limit;
@@ -106,7 +109,8 @@ static void free_all(Solver *s) {
     Buffers &b = s->b;
     void *ptrs[] = {b.posType[0], b.posType[1], b.velMass[0], b.velMass[1], b.restDensity[0], b.restDensity[1],
                     b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.v_star_alt, b.DF_factor, b.pstiff,
-                    b.error, b.reduce_tmp, b.aux4, b.pd, b.hash, b.slot,
+                    b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
+                    b.density_star, b.groupSorted, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
@@ -289,6 +293,14 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
         ALLOC(b.normal, N * 3 * R, true);
         ALLOC(b.group, N * sizeof(int), true);
         ALLOC(b.indexTable, N * sizeof(int), true);
+        // IISPH step (not available in slab solvers)
+        ALLOC(b.pressure_alt, N * R, true);
+        ALLOC(b.dii, N * 3 * R, true);
+        ALLOC(b.dijpjl, N * 3 * R, true);
+        ALLOC(b.pressureForce, N * 3 * R, true);
+        ALLOC(b.aii, N * R, true);
+        ALLOC(b.density_star, N * R, true);
+        ALLOC(b.groupSorted, N * sizeof(int), true);
     } else {
         ALLOC(b.orderKey[0], N * sizeof(long long), true);
         ALLOC(b.orderKey[1], N * sizeof(long long), true);
@@ -376,6 +388,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     invalidate_order(s);
     s->count_valid = false;
     s->owned_from_sort = false;
+    s->iisph = false;  // the per-position copy of group[] is rebuilt by the next IISPH call
     if (n == 0) return FSA_OK;
 
     Staging sp, sv, st, sm;
@@ -608,6 +621,14 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
     if (k == "DF_factor") { TRY(want(N * R)); return copy_out(s, s->b.DF_factor, dst, bytes); }
     if (k == "pstiff") { TRY(want(N * R)); return copy_out(s, s->b.pstiff, dst, bytes); }
     if (k == "error") { TRY(want(N * R)); return copy_out(s, s->b.error, dst, bytes); }
+    if (k == "dii" || k == "dijpjl" || k == "pressureForce" || k == "aii" || k == "density_star") {
+        if (s->slab) return fail(FSA_ERR_INVALID, "a slab solver has no IISPH buffers");
+        const bool vec = k == "dii" || k == "dijpjl" || k == "pressureForce";
+        TRY(want(N * (vec ? 3 : 1) * R));
+        const void *p = k == "dii" ? s->b.dii : k == "dijpjl" ? s->b.dijpjl : k == "pressureForce" ? s->b.pressureForce
+                        : k == "aii" ? s->b.aii : s->b.density_star;
+        return copy_out(s, p, dst, bytes);
+    }
     if (k == "restDensity") { TRY(want(N * R)); return copy_out(s, s->b.restDensity[c], dst, bytes); }
     if (k == "uniqueId") { TRY(want(N * sizeof(int))); return copy_out(s, s->b.uniqueId[c], dst, bytes); }
     if (k == "orderKey") {
@@ -685,6 +706,13 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     if (k == "DF_factor") return plain(s->b.DF_factor, N * R);
     if (k == "pstiff") return plain(s->b.pstiff, N * R);
     if (k == "error") return plain(s->b.error, N * R);
+    if (!s->slab) {
+        if (k == "dii") return plain(s->b.dii, N * 3 * R);
+        if (k == "dijpjl") return plain(s->b.dijpjl, N * 3 * R);
+        if (k == "pressureForce") return plain(s->b.pressureForce, N * 3 * R);
+        if (k == "aii") return plain(s->b.aii, N * R);
+        if (k == "density_star") return plain(s->b.density_star, N * R);
+    }
     if (k == "restDensity") return plain(s->b.restDensity[c], N * R);
     if (k == "pos" || k == "vel") {
         TRY(want(N * 3 * R));
@@ -841,6 +869,91 @@ int fsa_step_dfsph(fsa_solver *hs, int nsteps) {
         TRY(fsa_sort_particles(hs));
         TRY(fsa_compute_density_alpha(hs));
         TRY(fsa_correct_divergence_error(hs, 5, 1.0, nullptr, nullptr));
+    }
+    return FSA_OK;
+}
+
+// ---- IISPH -------------------------------------------------------------------------------------
+// Marks the solver as running the IISPH step: from then on every sort also carries pressure[] and keeps
+// the per-position copy of group[] current.  The first call brings that copy up to date.
+static int enter_iisph(Solver *s, const char *who) {
+    if (s->slab) return fail(FSA_ERR_INVALID, "%s is not available in a slab solver", who);
+    if (s->iisph) return FSA_OK;
+    s->iisph = true;
+    if (s->n == 0) return FSA_OK;
+    return launch_gather_by_uid(s, s->b.group, s->b.groupSorted, s->n, 1);
+}
+
+#define IISPH_ENTRY(name, launcher)                                                                  \
+    int name(fsa_solver *hs) {                                                                       \
+        Solver *s = reinterpret_cast<Solver *>(hs);                                                  \
+        NEED(s);                                                                                     \
+        TRY(enter_iisph(s, #name));                                                                  \
+        if (!s->sorted_valid) return fail(FSA_ERR_INVALID, #name " needs a sorted state");           \
+        return launcher(s);                                                                          \
+    }
+IISPH_ENTRY(fsa_non_pressure_force_multiphase, launch_npf_multiphase)
+IISPH_ENTRY(fsa_iisph_factor, launch_iisph_factor)
+IISPH_ENTRY(fsa_iisph_predict_density, launch_iisph_predict_density)
+IISPH_ENTRY(fsa_iisph_calc_dijpjl, launch_iisph_dijpjl)
+IISPH_ENTRY(fsa_iisph_calc_new_pressure, launch_iisph_new_pressure)
+IISPH_ENTRY(fsa_iisph_calc_pressure_force, launch_iisph_pressure_force)
+#undef IISPH_ENTRY
+
+int fsa_iisph_solve_pressure(fsa_solver *hs, int maxiter, int *rounds, double *last_mean) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (maxiter < 0) return fail(FSA_ERR_INVALID, "maxiter < 0");
+    double err_sum = 0.0;
+    int done = 0;
+    const bool f32 = s->precision == FSA_PRECISION_F32;
+    for (int iter = 0; iter < maxiter; iter++) {
+        TRY(fsa_iisph_calc_dijpjl(hs));
+        TRY(fsa_iisph_calc_new_pressure(hs));
+        done++;
+        const double last = err_sum;
+        TRY(launch_mean_error(s, &err_sum));
+        // solver/sph_solver.cu:1440: both tests on float values
+        const double a = std::fabs(err_sum);
+        const double b = f32 ? (double)std::fabs((float)err_sum - (float)last) : std::fabs(err_sum - last);
+        if (a < 1e-6 || b < 1e-6) break;
+    }
+    if (rounds) *rounds = done;
+    if (last_mean) *last_mean = err_sum;
+    return FSA_OK;
+}
+
+int fsa_iisph_update(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    TRY(fsa_iisph_calc_pressure_force(hs));
+    TRY(launch_iisph_integrate(s));
+    // positions moved: the cell ranges no longer describe them
+    s->sorted_valid = false;
+    s->hash_valid = false;
+    s->perm_valid = false;
+    s->pd_valid = false;
+    return FSA_OK;
+}
+
+int fsa_setup_iisph(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    TRY(enter_iisph(s, "fsa_setup_iisph"));
+    TRY(fsa_sort_particles(hs));
+    TRY(fsa_iisph_factor(hs));
+    return fsa_rigid_particle_volume(hs);
+}
+
+int fsa_step_iisph(fsa_solver *hs, int nsteps) {
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    for (int k = 0; k < nsteps; k++) {
+        TRY(fsa_non_pressure_force_multiphase(hs));
+        TRY(fsa_iisph_predict_density(hs));
+        TRY(fsa_iisph_solve_pressure(hs, 10, nullptr, nullptr));  // "temp 10", solver/sph_solver.cu:1416
+        TRY(fsa_iisph_update(hs));
+        TRY(fsa_sort_particles(hs));
+        TRY(fsa_iisph_factor(hs));
     }
     return FSA_OK;
 }

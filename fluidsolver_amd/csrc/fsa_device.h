@@ -45,7 +45,10 @@ template <typename T> struct DevParams {
     T sr;          // smoothradius
     T kspikydiff;
     T kernel_cubic;
+    T kernel_cubic_gradient;
     T kpoly6;
+    T surface_tension;
+    T boundary_friction;
     T pressureK;
     T boundary_visc;
     T accel_limit;

@@ -331,6 +331,7 @@ int launch_rank(Solver *s) {
 int launch_reorder(Solver *s) {
     if (s->n == 0) return FSA_OK;
     const int in = s->cur, out = 1 - s->cur;
+    {
     ScopedTimer t(s, "reorder");
     if (s->precision == FSA_PRECISION_F32)
         hipLaunchKernelGGL(reorder_kernel<float>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
@@ -345,8 +346,10 @@ int launch_reorder(Solver *s) {
                            (double4 *)s->b.posType[out], (double4 *)s->b.velMass[out], (double *)s->b.restDensity[out],
                            s->b.uniqueId[out], (Vec3<double> *)s->b.v_star_alt);
     FSA_HIP(hipGetLastError());
+    }
     std::swap(s->b.v_star, s->b.v_star_alt);
     if (s->slab) return launch_slab_keys(s);
+    if (s->iisph) return launch_iisph_carry(s, out);
     return FSA_OK;
 }
 

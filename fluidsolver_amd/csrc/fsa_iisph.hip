@@ -1,0 +1,552 @@
+// IISPH step for gfx950, fluid and rigid particles: the step the reference's MultiphaseSPHSolver runs by
+// default (SolveIISPH, solver/MultiphaseSPHSolver.cpp:173-188 under /root/reference/particle_solver).
+//
+// Replaces NonPressureForceKernel_Multiphase (solver/sph_kernel_impl.cuh:1126-1306), IISPHFactorKernel,
+// IISPHPredictDensityKernel, CalcDIJPJLKernel, CalcNewPressureKernel, CalcPressureForceKernel,
+// IISPHUpdateKernel (:3663-4076) and the host-side mean of error[] that IISPHSolvePressure takes after
+// copying the whole array to the host every round (solver/sph_solver.cu:1428-1436): here a two-level
+// device reduction returns one number.  Deformable and cloth particles are not covered: the kernels of
+// the step that act on them alone (ComputeTensionWithP_Kernel, UpdateSolidStateF_Kernel) are absent, and
+// the TYPE_DEFORMABLE pair term of the non-pressure pass (:1234-1237) is left out.
+//
+// Every pass is a policy run by the kernels of fsa_pass.h.  Arithmetic follows the reference text
+// operation for operation (explicit casts where its double literals promote a float expression).
+#include "fsa_pass.h"
+
+namespace fsa {
+
+// KernelGradient_Cubic :42-54; `q > EPSILON` compares in double, both polynomial branches are double
+// expressions rounded to T once.  r = sqrt(d2) with d2 = x*x + y*y + z*z, as xij.Norm() evaluates it.
+template <typename T>
+__device__ __forceinline__ void kernel_gradient_cubic(const DevParams<T> &P, T h, T x, T y, T z, T d2, T &gx, T &gy,
+                                                      T &gz) {
+    const T r = r_sqrt(d2);
+    const T q = r / h;
+    if (!(q < 2 && (double)q > FSA_EPSILON)) {
+        gx = gy = gz = 0;
+        return;
+    }
+    T df;
+    if (q >= 1)
+        df = (T)(0.5 * (double)(2 - q) * (double)(2 - q) * (-1));
+    else
+        df = (T)((double)(-2 * q) + 1.5 * (double)q * (double)q);
+    gx = x * df * P.kernel_cubic_gradient / r;
+    gy = y * df * P.kernel_cubic_gradient / r;
+    gz = z * df * P.kernel_cubic_gradient / r;
+}
+
+// the three `case` labels that share one body in every IISPH cell function
+__device__ __forceinline__ bool fluid_like(int t) {
+    return t == FSA_TYPE_FLUID || t == FSA_TYPE_DEFORMABLE || t == FSA_TYPE_CLOTH;
+}
+// neighbour types with a `case` of their own: 1 = inside the support
+__device__ __forceinline__ int iisph_reach(int tj) { return (fluid_like(tj) || tj == FSA_TYPE_RIGID) ? 1 : 0; }
+
+template <typename T> __device__ __forceinline__ T dot3(T ax, T ay, T az, T bx, T by, T bz) {
+    return ax * bx + ay * by + az * bz;
+}
+
+// d_ji of :3784 / :3925: gradW * -1 * mass_j / density_i / density_i * dt * dt * -1, per component
+template <typename T> __device__ __forceinline__ T dji_term(const DevParams<T> &P, T g, T mass_j, T dens_i) {
+    return g * (T)(-1) * mass_j / dens_i / dens_i * P.dt * P.dt * (T)(-1);
+}
+
+// ---- NonPressureForceCell_Multiphase :1126-1262 + NonPressureForceKernel_Multiphase :1264-1306 -------
+template <typename T> struct NpfMultiPolicy {
+    static __device__ __forceinline__ int reach(int) { return 1; }  // surface tension couples any two types
+    struct Self {
+        Vec4<T> v;  // velocity, mass
+        T fx, fy, fz, dens, rd;
+        int type, group;
+        T h, h2, support, fac, sr6;
+    };
+    struct Nb { Vec4<T> v; T dens; int group; };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID && type != FSA_TYPE_CLOTH; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &A, const DevParams<T> &P, int index) {
+        Vec3<T> vs{0, 0, 0};  // TYPE_RIGID, :1274-1277
+        if (unpack_int(A.posType[index].w) == FSA_TYPE_CLOTH) {  // :1279-1282
+            const Vec4<T> v = A.velMass[index];
+            vs.x = v.x + P.gravity[0] * P.dt;
+            vs.y = v.y + P.gravity[1] * P.dt;
+            vs.z = v.z + P.gravity[2] * P.dt;
+        }
+        A.vStarOut[index] = vs;
+    }
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        S.v = A.velMass[index];
+        S.fx = S.fy = S.fz = 0;
+        S.dens = A.density[index];
+        S.rd = A.restDensity[index];
+        S.type = unpack_int(A.posType[index].w);
+        S.group = A.groupSorted[index];
+        S.h = (T)((double)P.sr * 0.5);  // :1142
+        S.h2 = S.h * S.h;
+        S.support = S.h * 2;
+        // :1157, :1160; pow(float, int) taken as the double overload
+        S.fac = (T)(32.0f / 3.141593 / pow((double)S.support, 9.0));
+        S.sr6 = (T)(pow((double)P.sr, 6.0) / 64.0);
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        return Nb{A.velMass[j], A.density[j], A.groupSorted[j]};
+    }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &A, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int j, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        if (d2 >= S.h2 * 4 || (double)d2 < FSA_EPSILON) return;  // :1167 (leaves the particle itself out)
+        const T d = r_sqrt(d2);
+        T gx, gy, gz;
+        kernel_gradient_cubic(P, S.h, xx, xy, xz, d2, gx, gy, gz);
+        const T vx = S.v.x - nb.v.x, vy = S.v.y - nb.v.y, vz = S.v.z - nb.v.z;
+        const T volj = nb.v.w / nb.dens;
+        if (S.type == FSA_TYPE_FLUID && tj == FSA_TYPE_FLUID) {  // xsph artificial viscosity, :1205-1208
+            const T w = kernel_cubic_d2(P, S.h, d2);
+            T c;
+            if (S.group == 0 || nb.group == 0)
+                c = P.viscosity * volj * (T)(-1) * w / P.dt;
+            else
+                c = (T)(0.5 * (double)volj * (-1) * (double)w / (double)P.dt);
+            S.fx += vx * c;
+            S.fy += vy * c;
+            S.fz += vz * c;
+        }
+        if (S.group == nb.group) {  // surface tension, :1214-1232
+            const T c = S.support - d;
+            T sf_kernel;
+            if (d < S.h)
+                sf_kernel = 2 * c * c * c * d * d2 - S.sr6;
+            else if (d < S.support)
+                sf_kernel = c * c * c * d * d2;
+            else
+                sf_kernel = 0;
+            sf_kernel *= S.fac;
+            T tmp = P.surface_tension;
+            if (S.group == 4) tmp *= 10;
+            const T k = tmp * volj * sf_kernel / d * (T)(-1);
+            S.fx += xx * k;
+            S.fy += xy * k;
+            S.fz += xz * k;
+        }
+        if (tj == FSA_TYPE_RIGID && nb.group == 0) {  // wall viscosity and friction, :1239-1259
+            const T xv = dot3(vx, vy, vz, xx, xy, xz);
+            if (xv < 0) {
+                const Vec3<T> nj = A.normalById[A.uniqueId[j]];
+                const T rd_j = A.restDensity[j];
+                const T ndv = dot3(nj.x, nj.y, nj.z, vx, vy, vz);
+                const T tx = vx - nj.x * ndv, ty = vy - nj.y * ndv, tz = vz - nj.z * ndv;
+                const T visc = (T)((double)(P.boundary_visc * P.sr) * 88.5 / (double)S.dens * 0.25);
+                const T pi = (T)((double)(visc * xv) / ((double)d2 + 0.01 * (double)S.h2));
+                const T f0 = gx * pi * S.rd * rd_j, f1 = gy * pi * S.rd * rd_j, f2 = gz * pi * S.rd * rd_j;
+                const T fdn = dot3(f0, f1, f2, nj.x, nj.y, nj.z);
+                const T nx = nj.x * fdn, ny = nj.y * fdn, nz = nj.z * fdn;
+                const T k = r_sqrt(nx * nx + ny * ny + nz * nz) * (T)(-1) * P.boundary_friction;
+                S.fx += nx;
+                S.fy += ny;
+                S.fz += nz;
+                S.fx += tx * k;
+                S.fy += ty * k;
+                S.fz += tz * k;
+            }
+        }
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        S.fx += P.gravity[0];
+        S.fy += P.gravity[1];
+        S.fz += P.gravity[2];
+        Vec3<T> vs;
+        vs.x = S.v.x + S.fx * P.dt;
+        vs.y = S.v.y + S.fy * P.dt;
+        vs.z = S.v.z + S.fz * P.dt;
+        A.vStarOut[index] = vs;
+    }
+};
+
+// ---- IISPHFactorCell :3665-3715 + IISPHFactorKernel :3717-3749 ----------------------------------------
+template <typename T> struct IisphFactorPolicy {
+    static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
+    struct Self { T dens, sx, sy, sz, mass, rd; };
+    struct Nb { T rd; };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &, const DevParams<T> &, int) {}
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.dens = S.sx = S.sy = S.sz = 0;
+        S.mass = A.velMass[index].w;
+        S.rd = A.restDensity[index];
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.restDensity[j]}; }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        const T sr = P.sr, sr2 = sr * sr;
+        if (d2 >= sr2) return;
+        T gx, gy, gz;
+        kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
+        T mass_j;
+        if (fluid_like(tj))
+            mass_j = S.mass;
+        else if (tj == FSA_TYPE_RIGID)
+            mass_j = nb.rd * S.rd;
+        else
+            return;
+        S.sx += gx * mass_j;
+        S.sy += gy * mass_j;
+        S.sz += gz * mass_j;
+        S.dens += kernel_cubic_d2(P, sr / 2, d2) * mass_j;
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        A.densityOut[index] = S.dens;
+        const T k = P.dt * P.dt / S.dens / S.dens * (T)(-1);
+        A.dii[index] = Vec3<T>{S.sx * k, S.sy * k, S.sz * k};
+    }
+};
+
+// ---- IISPHPredictDensityCell :3751-3805 + IISPHPredictDensityKernel :3807-3833 ------------------------
+template <typename T> struct IisphPredictPolicy {
+    static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
+    struct Self { T dens, aii, dens_i, mass, rd; Vec3<T> vs, dii; };
+    struct Nb { T vx, vy, vz, rd; };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &, const DevParams<T> &, int) {}
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.dens_i = A.density[index];
+        S.dens = S.dens_i;
+        S.aii = 0;
+        S.mass = A.velMass[index].w;
+        S.rd = A.restDensity[index];
+        S.vs = A.vStarIn[index];
+        S.dii = A.dii[index];
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        const Vec3<T> v = A.vStarIn[j];
+        return Nb{v.x, v.y, v.z, A.restDensity[j]};
+    }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        const T sr = P.sr, sr2 = sr * sr;
+        if (d2 >= sr2) return;
+        T gx, gy, gz;
+        kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
+        T mass_j;
+        if (fluid_like(tj)) {
+            mass_j = S.mass;
+            S.dens += P.dt * mass_j * dot3(S.vs.x - nb.vx, S.vs.y - nb.vy, S.vs.z - nb.vz, gx, gy, gz);
+        } else if (tj == FSA_TYPE_RIGID) {
+            mass_j = nb.rd * S.rd;
+            S.dens += P.dt * mass_j * dot3(S.vs.x, S.vs.y, S.vs.z, gx, gy, gz);
+        } else {
+            return;
+        }
+        const T jx = dji_term(P, gx, mass_j, S.dens_i), jy = dji_term(P, gy, mass_j, S.dens_i),
+                jz = dji_term(P, gz, mass_j, S.dens_i);
+        S.aii += mass_j * dot3(S.dii.x - jx, S.dii.y - jy, S.dii.z - jz, gx, gy, gz);
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        A.pressureOut[index] = A.pressure[index] / 2;  // :3813
+        A.densityStar[index] = S.dens;
+        A.aii[index] = S.aii;
+    }
+};
+
+// ---- CalcDIJPJLCell :3835-3880 + CalcDIJPJLKernel :3882-3902 -----------------------------------------
+template <typename T> struct IisphDijpjlPolicy {
+    static __device__ __forceinline__ int reach(int tj) { return fluid_like(tj) ? 1 : 0; }  // `case TYPE_RIGID: break;`
+    struct Self { T ax, ay, az, mass; };
+    struct Nb { T dens, pressure; };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &, const DevParams<T> &, int) {}
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.ax = S.ay = S.az = 0;
+        S.mass = A.velMass[index].w;
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.density[j], A.pressure[j]}; }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        const T sr = P.sr, sr2 = sr * sr;
+        if (d2 >= sr2 || !fluid_like(tj)) return;
+        T gx, gy, gz;
+        kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
+        S.ax += gx * S.mass / nb.dens / nb.dens * nb.pressure * (T)(-1);
+        S.ay += gy * S.mass / nb.dens / nb.dens * nb.pressure * (T)(-1);
+        S.az += gz * S.mass / nb.dens / nb.dens * nb.pressure * (T)(-1);
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        const T k = P.dt * P.dt;
+        A.dijpjl[index] = Vec3<T>{S.ax * k, S.ay * k, S.az * k};
+    }
+};
+
+// ---- CalcNewPressureCell :3904-3959 + CalcNewPressureKernel :3961-3996 -------------------------------
+// The reference kernel overwrites pressure[index] while other threads still read pressure[j] from the
+// same array, so what a neighbour sees there depends on scheduling.  Here every particle reads the
+// previous round's pressures (Jacobi): the new values go to a second array that the launcher swaps in.
+template <typename T> struct IisphNewPressurePolicy {
+    static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
+    struct Self { T lll, p_i, dens_i, mass, rd; Vec3<T> dijpjl; };
+    struct Nb { Vec3<T> dii, dijpjl; T pressure, rd; };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &A, const DevParams<T> &, int index) {
+        A.errorOut[index] = 0;  // :3965-3969
+        A.pressureOut[index] = A.pressure[index];
+    }
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.lll = 0;
+        S.p_i = A.pressure[index];
+        S.dens_i = A.density[index];
+        S.mass = A.velMass[index].w;
+        S.rd = A.restDensity[index];
+        S.dijpjl = A.dijpjl[index];
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        return Nb{A.dii[j], A.dijpjl[j], A.pressure[j], A.restDensity[j]};
+    }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        const T sr = P.sr, sr2 = sr * sr;
+        if (d2 >= sr2) return;
+        T gx, gy, gz;
+        kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
+        if (fluid_like(tj)) {
+            const T mass_j = S.mass;
+            const T jx = dji_term(P, gx, mass_j, S.dens_i), jy = dji_term(P, gy, mass_j, S.dens_i),
+                    jz = dji_term(P, gz, mass_j, S.dens_i);
+            const T lx = S.dijpjl.x - nb.dii.x * nb.pressure - nb.dijpjl.x + jx * S.p_i;
+            const T ly = S.dijpjl.y - nb.dii.y * nb.pressure - nb.dijpjl.y + jy * S.p_i;
+            const T lz = S.dijpjl.z - nb.dii.z * nb.pressure - nb.dijpjl.z + jz * S.p_i;
+            S.lll += mass_j * dot3(lx, ly, lz, gx, gy, gz);
+        } else if (tj == FSA_TYPE_RIGID) {
+            const T mass_j = nb.rd * S.rd;
+            S.lll += mass_j * dot3(S.dijpjl.x, S.dijpjl.y, S.dijpjl.z, gx, gy, gz);
+        }
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        const T prev = S.p_i;
+        T density_corr = A.densityStar[index] + S.lll;
+        const T aii = A.aii[index];
+        T np;
+        if ((double)(aii < 0 ? -aii : aii) > 1e-8) {
+            np = (T)(0.5 * (double)prev + 0.5 * (double)(S.rd - density_corr) / (double)aii);
+            if (np < 0) np = 0;
+        } else {
+            np = 0;
+        }
+        A.pressureOut[index] = np;
+        density_corr += prev * aii;
+        A.errorOut[index] = density_corr;
+    }
+};
+
+// ---- CalcPressureForceCell :3998-4046 + CalcPressureForceKernel :4048-4065 ---------------------------
+template <typename T> struct IisphPressureForcePolicy {
+    static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
+    struct Self { T fx, fy, fz, p_i, dens_i, mass, rd; };
+    struct Nb { T pressure, dens, rd; };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &, const DevParams<T> &, int) {}
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.fx = S.fy = S.fz = 0;
+        S.p_i = A.pressure[index];
+        S.dens_i = A.density[index];
+        S.mass = A.velMass[index].w;
+        S.rd = A.restDensity[index];
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        return Nb{A.pressure[j], A.density[j], A.restDensity[j]};
+    }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        const T sr = P.sr, sr2 = sr * sr;
+        if (d2 >= sr2) return;
+        T gx, gy, gz;
+        kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
+        if (fluid_like(tj)) {
+            const T mass_j = S.mass;
+            const T w = S.p_i / S.dens_i / S.dens_i + nb.pressure / nb.dens / nb.dens;
+            S.fx += gx * (T)(-1) * mass_j * mass_j * w;
+            S.fy += gy * (T)(-1) * mass_j * mass_j * w;
+            S.fz += gz * (T)(-1) * mass_j * mass_j * w;
+        } else if (tj == FSA_TYPE_RIGID) {
+            const T mass_j = nb.rd * S.rd;
+            const T w = S.p_i / S.dens_i / S.dens_i;
+            S.fx += gx * (T)(-1) * S.mass * mass_j * w;
+            S.fy += gy * (T)(-1) * S.mass * mass_j * w;
+            S.fz += gz * (T)(-1) * S.mass * mass_j * w;
+        }
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        A.pressureForce[index] = Vec3<T>{S.fx, S.fy, S.fz};
+    }
+};
+
+// IISPHUpdateKernel :4067-4076
+template <typename T>
+__global__ __launch_bounds__(kBlock) void iisph_integrate_kernel(DevParams<T> P, int n, Vec4<T> *__restrict__ posType,
+                                                                 Vec4<T> *__restrict__ velMass,
+                                                                 const Vec3<T> *__restrict__ v_star,
+                                                                 const Vec3<T> *__restrict__ pressureForce) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    Vec4<T> p = posType[index];
+    if (unpack_int(p.w) == FSA_TYPE_RIGID) return;
+    Vec4<T> v = velMass[index];
+    const Vec3<T> vs = v_star[index], pf = pressureForce[index];
+    v.x = vs.x + pf.x * P.dt / v.w;
+    v.y = vs.y + pf.y * P.dt / v.w;
+    v.z = vs.z + pf.z * P.dt / v.w;
+    p.x += v.x * P.dt;
+    p.y += v.y * P.dt;
+    p.z += v.z * P.dt;
+    velMass[index] = v;
+    posType[index] = p;
+}
+
+// The sort of the IISPH step also carries pressure[] (sorted_pressure, solver/sph_kernel_impl.cuh:175-198
+// and MultiphaseSPHSolver.cpp:99); group[] is kept in uniqueId order and gathered for the sorted positions.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void iisph_carry_kernel(int n, const int *__restrict__ sortedIndex,
+                                                             const int *__restrict__ uniqueIdSorted,
+                                                             const int *__restrict__ groupById,
+                                                             const T *__restrict__ pressureIn,
+                                                             T *__restrict__ pressureOut,
+                                                             int *__restrict__ groupSorted) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    pressureOut[p] = pressureIn[sortedIndex[p]];
+    groupSorted[p] = groupById[uniqueIdSorted[p]];
+}
+
+// sum over error[] in double: per-block sums, then one block over those
+template <typename T>
+__global__ __launch_bounds__(kBlock) void block_sum_kernel(int n, const T *__restrict__ in, double *__restrict__ out) {
+    __shared__ double part[kBlock / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) acc += (double)in[i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) acc += part[w];
+        out[blockIdx.x] = acc;
+    }
+}
+
+#define IISPH_PASS(PolicyName, tag)                                              \
+    do {                                                                         \
+        if (s->n == 0) return FSA_OK;                                            \
+        if (use_tiles(s)) return launch_tuned<PolicyName<float>>(s, tag);        \
+        DF_GENERIC(PolicyName<T>, tag);                                          \
+        return FSA_OK;                                                           \
+    } while (0)
+
+int launch_npf_multiphase(Solver *s) { IISPH_PASS(NpfMultiPolicy, "npf_multiphase"); }
+int launch_iisph_factor(Solver *s) { IISPH_PASS(IisphFactorPolicy, "iisph_factor"); }
+int launch_iisph_predict_density(Solver *s) { IISPH_PASS(IisphPredictPolicy, "iisph_predict"); }
+int launch_iisph_dijpjl(Solver *s) { IISPH_PASS(IisphDijpjlPolicy, "iisph_dijpjl"); }
+int launch_iisph_pressure_force(Solver *s) { IISPH_PASS(IisphPressureForcePolicy, "iisph_pforce"); }
+
+int launch_iisph_new_pressure(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    {
+        ScopedTimer t(s, "iisph_new_pressure");
+        const int unit = kXcds << xcd_run_log();
+        if (use_tiles(s)) {
+            PassArrays<float> A = arrays_of<float>(s);
+            A.pressureOut = (float *)s->b.pressure_alt;
+            const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+            hipLaunchKernelGGL((tuned_pass_kernel<IisphNewPressurePolicy<float>, kTunedBS, kRowCap, kQueueDf>), dim3(nb),
+                               dim3(kTunedBS), 0, s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash,
+                               xcd_run_log());
+        } else if (s->precision == FSA_PRECISION_F32) {
+            PassArrays<float> A = arrays_of<float>(s);
+            A.pressureOut = (float *)s->b.pressure_alt;
+            hipLaunchKernelGGL((generic_pass_kernel<float, IisphNewPressurePolicy<float>>), dim3(blocks_for(s->n)),
+                               dim3(kBlock), 0, s->stream, s->pf, s->n, A, s->b.cellStart);
+        } else {
+            PassArrays<double> A = arrays_of<double>(s);
+            A.pressureOut = (double *)s->b.pressure_alt;
+            hipLaunchKernelGGL((generic_pass_kernel<double, IisphNewPressurePolicy<double>>), dim3(blocks_for(s->n)),
+                               dim3(kBlock), 0, s->stream, s->pd, s->n, A, s->b.cellStart);
+        }
+        FSA_HIP(hipGetLastError());
+    }
+    std::swap(s->b.pressure, s->b.pressure_alt);
+    return FSA_OK;
+}
+
+int launch_iisph_integrate(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "iisph_integrate");
+    const int c = s->cur;
+    DF_DISPATCH(iisph_integrate_kernel, (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
+                (const Vec3<T> *)s->b.v_star, (const Vec3<T> *)s->b.pressureForce);
+    return FSA_OK;
+}
+
+// `uid_buffer`: which copy of uniqueId holds the sorted ids (the reorder calls this before the flip)
+int launch_iisph_carry(Solver *s, int uid_buffer) {
+    if (s->n == 0) return FSA_OK;
+    {
+        ScopedTimer t(s, "iisph_carry");
+        if (s->precision == FSA_PRECISION_F32)
+            hipLaunchKernelGGL(iisph_carry_kernel<float>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                               s->b.sortedIndex, s->b.uniqueId[uid_buffer], s->b.group, (const float *)s->b.pressure,
+                               (float *)s->b.pressure_alt, s->b.groupSorted);
+        else
+            hipLaunchKernelGGL(iisph_carry_kernel<double>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                               s->b.sortedIndex, s->b.uniqueId[uid_buffer], s->b.group, (const double *)s->b.pressure,
+                               (double *)s->b.pressure_alt, s->b.groupSorted);
+        FSA_HIP(hipGetLastError());
+    }
+    std::swap(s->b.pressure, s->b.pressure_alt);
+    return FSA_OK;
+}
+
+constexpr int kSumBlocks = 1024;
+
+// Mean of error[] over all particles (IISPHSolvePressure, solver/sph_solver.cu:1428-1436).  Variant 0
+// copies the array to the host and adds it up in a float, in index order, exactly as the reference does;
+// the other variants reduce on the device in double and round the mean once.
+int launch_mean_error(Solver *s, double *out) {
+    *out = 0.0;
+    if (s->n == 0) return FSA_OK;
+    const int n = s->n;
+    if (s->variant == 0) {
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        if (s->precision == FSA_PRECISION_F32) {
+            std::vector<float> e((size_t)n);
+            FSA_HIP(hipMemcpy(e.data(), s->b.error, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+            float sum = 0.f;
+            for (int i = 0; i < n; i++) sum += e[i];
+            sum /= n;
+            *out = sum;
+        } else {
+            std::vector<double> e((size_t)n);
+            FSA_HIP(hipMemcpy(e.data(), s->b.error, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+            double sum = 0.0;
+            for (int i = 0; i < n; i++) sum += e[i];
+            sum /= n;
+            *out = sum;
+        }
+        return FSA_OK;
+    }
+    {
+        ScopedTimer t(s, "mean_error");
+        const int nb = std::min(kSumBlocks, blocks_for(n));
+        double *tmp = (double *)s->b.reduce_tmp;
+        if (s->precision == FSA_PRECISION_F32)
+            hipLaunchKernelGGL(block_sum_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, n,
+                               (const float *)s->b.error, tmp);
+        else
+            hipLaunchKernelGGL(block_sum_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, n,
+                               (const double *)s->b.error, tmp);
+        hipLaunchKernelGGL(block_sum_kernel<double>, dim3(1), dim3(kBlock), 0, s->stream, nb, (const double *)tmp,
+                           tmp + kSumBlocks);
+        FSA_HIP(hipGetLastError());
+    }
+    double sum = 0.0;
+    FSA_HIP(hipMemcpyAsync(&sum, (const double *)s->b.reduce_tmp + kSumBlocks, sizeof(sum), hipMemcpyDeviceToHost,
+                           s->stream));
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    const double mean = sum / (double)n;
+    *out = s->precision == FSA_PRECISION_F32 ? (double)(float)mean : mean;
+    return FSA_OK;
+}
+
+}  // namespace fsa

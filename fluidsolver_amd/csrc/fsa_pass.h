@@ -1,0 +1,311 @@
+// Runner kernels of the neighbour passes that are written as policies (DFSPH, IISPH and the WCSPH
+// density pass of scenes with rigid particles): the policy holds the loop body of one of the
+// reference's *Cell functions, the kernels here walk the 27 cells in the reference's order.
+#pragma once
+
+#include <algorithm>
+#include <type_traits>
+
+#include "fsa_pair.h"
+#include "fsa_solver.h"
+#include "fsa_tile.h"
+
+namespace fsa {
+
+// Every neighbour pass of the step is written once, as a policy: which particles it covers, what it
+// reads of a neighbour, the loop body of the reference's *Cell function (`pair`), and what it stores.
+// Two kernels run a policy: generic_pass_kernel (one thread per particle, neighbours straight from
+// global memory; any precision) and tuned_pass_kernel (fp32: the LDS row tiles and per-lane hit queues
+// of the WCSPH force pass).  Both call the same `pair` in the same neighbour order, so they give the
+// same bits.
+template <typename T> struct PassArrays {
+    const Vec4<T> *posType;
+    const Vec4<T> *velMass;
+    const T *restDensity;
+    const T *density;
+    const T *dfFactor;
+    const T *pstiffIn;
+    const Vec3<T> *vStarIn;
+    const Vec4<T> *aux4;  // {v_star, mass} per particle (tuned density-change passes)
+    const T *aux2;        // {pstiff / density, mass} pairs (tuned applyPStiff)
+    T *densityOut;
+    T *dfFactorOut;
+    T *errorOut;
+    T *pstiffOut;
+    Vec3<T> *vStarOut;
+    // IISPH
+    const int *uniqueId;
+    const int *groupSorted;   // group of the particle at each sorted position
+    const Vec3<T> *normalById;  // indexed by uniqueId
+    const T *pressure;
+    T *pressureOut;
+    Vec3<T> *dii;
+    Vec3<T> *dijpjl;
+    T *aii;
+    T *densityStar;
+    Vec3<T> *pressureForce;
+};
+
+// One particle against its 27 cells in the reference's order, neighbours from global memory.
+template <typename T, typename Policy>
+__device__ __forceinline__ void generic_walk(const DevParams<T> &P, const PassArrays<T> &A, int index,
+                                             const Vec4<T> &pi, const int *__restrict__ cellStart,
+                                             typename Policy::Self &S) {
+    const RowWalk<T> walk(P, pi.x, pi.y, pi.z);
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+            int start, end;
+            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
+            for (int j = start; j < end; j++) {
+                const Vec4<T> pj = A.posType[j];
+                const int tj = unpack_int(pj.w);
+                if (Policy::reach(tj) == 0) continue;
+                const T xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const T d2 = xx * xx + xy * xy + xz * xz;
+                Policy::pair(A, P, S, j == index, tj, j, xx, xy, xz, d2, pj, Policy::load(A, j));
+            }
+        }
+}
+
+template <typename T, typename Policy>
+__global__ __launch_bounds__(kBlock) void generic_pass_kernel(DevParams<T> P, int n, PassArrays<T> A,
+                                                              const int *__restrict__ cellStart) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    const Vec4<T> pi = A.posType[index];
+    if (!Policy::wants(unpack_int(pi.w))) {
+        Policy::skip(A, P, index);
+        return;
+    }
+    typename Policy::Self S;
+    Policy::init(A, P, index, S);
+    generic_walk<T, Policy>(P, A, index, pi, cellStart, S);
+    Policy::finish(A, P, index, S);
+}
+
+// The tiled flavour (fp32): row tiles in LDS, each lane culls its range of every row into a queue of
+// 16-bit (row, index) entries, the queue is drained in double-buffered batches of gathered neighbours.
+// Candidates enter the queue on a fused squared distance with a little slack; `pair` then applies the
+// reference's own tests, in queue (= reference) order.
+template <typename Policy, int BS, int ROWCAP, int Q>
+__global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int n, PassArrays<float> A,
+                                                        const int *__restrict__ cellStart,
+                                                        const int *__restrict__ sortedHash, int xcd_log) {
+    using Shared = RowShared<BS, ROWCAP, true>;
+    __shared__ Shared sh;
+    __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
+    const int tid = threadIdx.x;
+    const int b0 = xcd_block(xcd_log) * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int nb = min(BS, n - b0);
+    const int index = b0 + tid;
+    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool active = false;
+    if (index < n) {
+        pi = A.posType[index];
+        active = Policy::wants(unpack_int(pi.w));
+        if (!active) Policy::skip(A, P, index);
+    }
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
+    typename Policy::Self S;
+    if (active) Policy::init(A, P, index, S);
+    if (!staged) {
+        if (active) {
+            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+            Policy::finish(A, P, index, S);
+        }
+        return;
+    }
+    const float sr = P.sr, sr2c = sr * sr * 1.000002f;
+    const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
+    unsigned short *const q = queue + tid;
+    const int safe = index < n ? index : 0;
+    int cnt = 0;
+
+    struct Batch {
+        int j[kDrainBatch];
+        float4 pj[kDrainBatch];
+        typename Policy::Nb nb[kDrainBatch];
+    };
+    auto batch_load = [&](Batch &B, int s) {
+#pragma unroll
+        for (int u = 0; u < kDrainBatch; u++) {
+            const int e = q[(s + u) * BS];
+            B.j[u] = s + u < cnt ? sh.rowStartG[e >> 9] + (e & 511) : safe;
+        }
+#pragma unroll
+        for (int u = 0; u < kDrainBatch; u++) {
+            B.pj[u] = A.posType[B.j[u]];
+            B.nb[u] = Policy::load(A, B.j[u]);
+        }
+    };
+    auto batch_eval = [&](const Batch &B, int s) {
+#pragma unroll
+        for (int u = 0; u < kDrainBatch; u++)
+            if (s + u < cnt) {
+                const float xx = pi.x - B.pj[u].x, xy = pi.y - B.pj[u].y, xz = pi.z - B.pj[u].z;
+                const float d2 = xx * xx + xy * xy + xz * xz;
+                Policy::pair(A, P, S, B.j[u] == index, unpack_int(B.pj[u].w), B.j[u], xx, xy, xz, d2, B.pj[u], B.nb[u]);
+            }
+    };
+    auto drain = [&]() {
+        Batch B0, B1;
+        batch_load(B0, 0);
+        for (int s = 0; wave_any(s < cnt); s += 2 * kDrainBatch) {
+            batch_load(B1, s + kDrainBatch);
+            batch_eval(B0, s);
+            if (!wave_any(s + kDrainBatch < cnt)) break;
+            batch_load(B0, s + 2 * kDrainBatch);
+            batch_eval(B1, s + kDrainBatch);
+        }
+        cnt = 0;
+    };
+
+    float4 e0, e1;
+    int lj, le, nlj = 0, nle = 0;
+    row_fetch<BS, ROWCAP, false>(sh, 0, A.posType, e0, e1);
+    lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+    row_store<BS, ROWCAP, true>(sh, 0, e0, e1);
+    __syncthreads();
+    for (int r = 0; r < 9; r++) {
+        const int buf = r & 1;
+        if (r + 1 < 9) {
+            row_fetch<BS, ROWCAP, false>(sh, r + 1, A.posType, e0, e1);
+            lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+        }
+        const int tag = r << 9;
+        auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            float d2[kChunk];
+            group_d2<true>(sh.x[buf][g], sh.y[buf][g], sh.z[buf][g], pi.x, pi.y, pi.z, d2);
+            const int4 T4 = sh.t[buf][g];
+            const int tj[kChunk] = {T4.x, T4.y, T4.z, T4.w};
+            const int etag = tag | (g * kChunk);
+            if (!wave_any((T4.x | T4.y | T4.z | T4.w) != 0)) {
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    q[cnt * BS] = (unsigned short)(etag + u);  // a miss is overwritten by the next store
+                    cnt += (d2[u] < sr2c && (!MASKED || (u >= lo && u < hi))) ? 1 : 0;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    const bool mine = !MASKED || (u >= lo && u < hi);
+                    const int reach = Policy::reach(tj[u]);
+                    if (mine && ((reach == 1 && d2[u] < sr2c) || reach == 2)) {
+                        q[cnt * BS] = (unsigned short)(etag + u);
+                        cnt++;
+                    }
+                }
+            }
+        };
+        const bool has = lj < le;
+        int base = lj & ~(kChunk - 1);
+        if (wave_any(has)) {
+            cull_group(has ? base / kChunk : Shared::kPad, lj - base, le - base, std::true_type());
+            if (wave_any(cnt > Q - kChunk)) drain();
+        }
+        base = has ? base + kChunk : le;
+        while (wave_any(base + kChunk <= le)) {
+            const bool go = base + kChunk <= le;
+            cull_group(go ? base / kChunk : Shared::kPad, 0, kChunk, std::false_type());
+            base += go ? kChunk : 0;
+            if (wave_any(cnt > Q - kChunk)) drain();
+        }
+        if (wave_any(base < le)) {
+            const int rem = le - base;
+            cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
+            if (wave_any(cnt > Q - kChunk)) drain();
+        }
+        if (r + 1 < 9) {
+            row_store<BS, ROWCAP, true>(sh, buf ^ 1, e0, e1);
+            lj = nlj;
+            le = nle;
+            __syncthreads();
+        }
+    }
+    drain();
+    if (active) Policy::finish(A, P, index, S);
+}
+
+static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+#define DF_DISPATCH(kernel, ...)                                                                                  \
+    do {                                                                                                          \
+        if (s->precision == FSA_PRECISION_F32) {                                                                  \
+            using T = float;                                                                                      \
+            const DevParams<T> &P = s->pf;                                                                        \
+            hipLaunchKernelGGL(kernel<T>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, P, s->n, __VA_ARGS__); \
+        } else {                                                                                                  \
+            using T = double;                                                                                     \
+            const DevParams<T> &P = s->pd;                                                                        \
+            hipLaunchKernelGGL(kernel<T>, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, P, s->n, __VA_ARGS__); \
+        }                                                                                                         \
+        FSA_HIP(hipGetLastError());                                                                               \
+    } while (0)
+
+template <typename T> static PassArrays<T> arrays_of(Solver *s) {
+    const int c = s->cur;
+    PassArrays<T> A{};
+    A.posType = (const Vec4<T> *)s->b.posType[c];
+    A.velMass = (const Vec4<T> *)s->b.velMass[c];
+    A.restDensity = (const T *)s->b.restDensity[c];
+    A.density = (const T *)s->b.density;
+    A.dfFactor = (const T *)s->b.DF_factor;
+    A.pstiffIn = (const T *)s->b.pstiff;
+    A.vStarIn = (const Vec3<T> *)s->b.v_star;
+    A.aux4 = (const Vec4<T> *)s->b.aux4;
+    A.aux2 = (const T *)s->b.pd;
+    A.densityOut = (T *)s->b.density;
+    A.dfFactorOut = (T *)s->b.DF_factor;
+    A.errorOut = (T *)s->b.error;
+    A.pstiffOut = (T *)s->b.pstiff;
+    A.vStarOut = (Vec3<T> *)s->b.v_star;
+    A.uniqueId = s->b.uniqueId[c];
+    A.groupSorted = s->b.groupSorted;
+    A.normalById = (const Vec3<T> *)s->b.normal;
+    A.pressure = (const T *)s->b.pressure;
+    A.pressureOut = (T *)s->b.pressure;
+    A.dii = (Vec3<T> *)s->b.dii;
+    A.dijpjl = (Vec3<T> *)s->b.dijpjl;
+    A.aii = (T *)s->b.aii;
+    A.densityStar = (T *)s->b.density_star;
+    A.pressureForce = (Vec3<T> *)s->b.pressureForce;
+    return A;
+}
+
+constexpr int kQueueDf = 48;  // 16-bit slots, as in the WCSPH force pass
+
+static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F32 && s->variant >= 1; }
+
+// Policy<float> through the tiled kernel
+template <typename Policy> static int launch_tuned(Solver *s, const char *tag) {
+    ScopedTimer t(s, tag);
+    const int unit = kXcds << xcd_run_log();
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
+                       s->stream, s->pf, s->n, arrays_of<float>(s), s->b.cellStart, s->b.sortedHash, xcd_run_log());
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// Policy<T> through the one-thread-per-particle kernel, either precision
+#define DF_GENERIC(PolicyT, tag)                                                                           \
+    do {                                                                                                   \
+        ScopedTimer t(s, tag);                                                                             \
+        if (s->precision == FSA_PRECISION_F32) {                                                           \
+            using T = float;                                                                               \
+            hipLaunchKernelGGL((generic_pass_kernel<T, PolicyT>), dim3(blocks_for(s->n)), dim3(kBlock), 0, \
+                               s->stream, s->pf, s->n, arrays_of<T>(s), s->b.cellStart);                   \
+        } else {                                                                                           \
+            using T = double;                                                                              \
+            hipLaunchKernelGGL((generic_pass_kernel<T, PolicyT>), dim3(blocks_for(s->n)), dim3(kBlock), 0, \
+                               s->stream, s->pd, s->n, arrays_of<T>(s), s->b.cellStart);                   \
+        }                                                                                                  \
+        FSA_HIP(hipGetLastError());                                                                        \
+    } while (0)
+
+}  // namespace fsa

@@ -34,6 +34,14 @@ struct Buffers {
     void *error = nullptr;
     void *reduce_tmp = nullptr;  // block maxima of error[]
     void *aux4 = nullptr;        // {v_star, mass} per particle for the tiled DFSPH passes
+    // IISPH step
+    void *pressure_alt = nullptr;  // the sort and the relaxed-Jacobi pressure update write here, then swap
+    void *dii = nullptr;           // tight 3-vectors
+    void *dijpjl = nullptr;        // tight 3-vectors
+    void *pressureForce = nullptr; // tight 3-vectors
+    void *aii = nullptr;
+    void *density_star = nullptr;
+    int *groupSorted = nullptr;    // group[] gathered into sorted order after each sort
     void *pd = nullptr;      // {pressure / density^2, density} pairs for the tuned force pass
     // neighbour search
     int *hash = nullptr;         // cell of particle i (device order before the sort)
@@ -87,6 +95,7 @@ struct Solver {
     bool pd_valid = false;  // pd[] matches density / pressure / mass of the current arrays ...
     bool pd_fast = false;   // ... in the fast flavour's layout
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
+    bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
     int variant = 2;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32
@@ -138,6 +147,15 @@ int launch_apply_pstiff(Solver *s);
 int launch_update_position(Solver *s);
 int launch_update_velocities(Solver *s);
 int launch_max_error(Solver *s, double start, double *out);  // synchronises
+int launch_iisph_carry(Solver *s, int uid_buffer);  // part of the reorder when s->iisph
+int launch_npf_multiphase(Solver *s);
+int launch_iisph_factor(Solver *s);
+int launch_iisph_predict_density(Solver *s);
+int launch_iisph_dijpjl(Solver *s);
+int launch_iisph_new_pressure(Solver *s);
+int launch_iisph_pressure_force(Solver *s);
+int launch_iisph_integrate(Solver *s);
+int launch_mean_error(Solver *s, double *out);  // synchronises
 int launch_density_tuned(Solver *s);
 int launch_density_rigid_tuned(Solver *s);
 int launch_force_tuned(Solver *s);

@@ -254,6 +254,37 @@ def ball_drop(center=(0.0, 0.30, 0.0), radius=0.10, floor=True) -> dict:
     return sc
 
 
+# <SurfaceTension> of the shipped scene 2 (config/sph_scene.xml:71); <BoundInfo> / <Friction> exist only in
+# the last scene of that file (:333-334), the shipped scene reads 0 for both
+IISPH_PARAMS = dict(surface_tension=100.0, boundary_visc=0.0, boundary_friction=0.0)
+
+
+def iisph_tank(nx, ny, nz, wall_group=1, fluid_groups=(0,), spacing=0.005, margin=4, head_room=2.0, **over) -> dict:
+    """A scene for the IISPH step: nx x ny x nz fluid particles per entry of `fluid_groups` (blocks side by
+    side along x, each with its own group id) standing in an OpenBox of TYPE_RIGID particles (LoadPO,
+    MultiphaseSPHSolver.cpp:750-768: mass = 2 spacing^3 restdensity, group = the object's id, normals
+    pointing inwards), as SetupFluidScene :815-835 builds the shipped scene."""
+    s = float(spacing)
+    parts = []
+    x0 = 0.0
+    for g in fluid_groups:
+        lo = (x0, 0.0, 0.0)
+        hi = (x0 + (nx - 0.5) * s, (ny - 0.5) * s, (nz - 0.5) * s)
+        parts.append(fluid_block(lo, hi, s, REF_PARAMS["restdensity"], group=int(g)))
+        x0 += nx * s
+    b_lo = (-1.2 * s, -1.2 * s, -1.2 * s)
+    b_hi = (x0 + 0.2 * s, ny * s * head_room, (nz + 0.2) * s)
+    parts.append(open_box(b_lo, b_hi, s, group=int(wall_group), ptype=TYPE_RIGID,
+                          mass=rigid_mass(s, REF_PARAMS["restdensity"]), rest_density=0.0))
+    sr = s * REF_PARAMS["smoothratio"]
+    vmin = tuple(v - margin * sr for v in b_lo)
+    # a whole number of cells per axis
+    vmax = tuple(lo + np.ceil((hi + margin * sr - lo) / sr) * sr for lo, hi in zip(vmin, b_hi))
+    prm = dict(IISPH_PARAMS)
+    prm.update(over)
+    return _finish(parts, _params(vmin, vmax, **prm))
+
+
 def read_raw_bounding_sphere(path):
     """RAW triangle soup, 9 floats per line (the format ObjReader::readraw parses,
     catpaw/objbuilder.cpp:150-187): returns (centre, radius) of the vertex cloud."""

@@ -85,6 +85,9 @@ typedef struct fsa_params {
     int slab_z0;
     int slab_nz;
     double kpoly6; /* DFSPH density kernel constant (solver/MultiphaseSPHSolver.cpp:464) */
+    /* IISPH non-pressure forces: <SurfaceTension> and <Friction> (solver/MultiphaseSPHSolver.cpp:393, 429) */
+    double surface_tension;
+    double boundary_friction;
 } fsa_params;
 
 typedef struct fsa_solver fsa_solver;
@@ -172,7 +175,7 @@ int fsa_readback_pos_color(fsa_solver *s, void *pos3, void *color4, int *n);
  * gridCellEnd (num_cells ints; gridCellEnd is only meaningful where
  * gridCellStart != 0xffffffff, as in the reference); cellStartDense
  * (num_cells + 1 ints, exclusive prefix of the per-cell counts); orderKey (n 64-bit ints, slab
- * solvers only); DF_factor pstiff error (n reals, DFSPH).
+ * solvers only); DF_factor pstiff error (n reals, DFSPH); the IISPH buffers listed further down.
  * `bytes` must be the exact size.  Both synchronise.
  */
 int fsa_get_buffer(fsa_solver *s, const char *name, void *dst, size_t bytes);
@@ -209,6 +212,46 @@ int fsa_setup_dfsph(fsa_solver *s);
 /* nsteps x SPHSolver::SolveDFSPH (solver/sph_solver.cpp:108-120, 5 rounds, threshold 1) without the
  * host read-back of positions */
 int fsa_step_dfsph(fsa_solver *s, int nsteps);
+
+/* ---- IISPH step (fluid and rigid particles) ----------------------------
+ *
+ * The step MultiphaseSPHSolver::Step runs by default (SolveIISPH, solver/MultiphaseSPHSolver.cpp:173-188),
+ * one entry per launcher of solver/sph_solver.cu:300-310 and :1388-1457.  Covered particle types:
+ * TYPE_FLUID and TYPE_RIGID (deformable / cloth bodies and their kernels are not).  Extra named buffers
+ * for fsa_get_buffer / fsa_set_buffer: dii dijpjl pressureForce (n x 3 reals), aii density_star (n reals).
+ * From the first of these calls after an upload on, every sort also carries pressure[] (the
+ * reference's sorted_pressure copy).  All need a sorted state.  Not available in slab solvers.
+ *
+ * density[] of TYPE_RIGID particles is never written by this step but read by the surface-tension term
+ * for a wall in the fluid's group (solver/sph_kernel_impl.cuh:1173, 1214-1232); the reference leaves it
+ * uninitialised, here it is whatever fsa_upload / fsa_set_buffer left (zero after an upload).
+ */
+/* NonPressureForce_Multiphase: XSPH viscosity, surface tension, wall viscosity + friction, gravity -> v_star */
+int fsa_non_pressure_force_multiphase(fsa_solver *s);
+/* IISPHFactor: cubic-spline density and d_ii */
+int fsa_iisph_factor(fsa_solver *s);
+/* IISPHPredictDensity: pressure /= 2 (warm start), density_star, a_ii */
+int fsa_iisph_predict_density(fsa_solver *s);
+/* the two kernels of one relaxation round (CalcDIJPJLKernel, CalcNewPressureKernel).  The reference's
+ * CalcNewPressureKernel updates pressure[] in place while neighbours read it (a race); here every
+ * particle reads the previous round's values. */
+int fsa_iisph_calc_dijpjl(fsa_solver *s);
+int fsa_iisph_calc_new_pressure(fsa_solver *s);
+/* IISPHSolvePressure (solver/sph_solver.cu:1409-1443, maxiter = 10 there): rounds until the mean of error[]
+ * is below 1e-6 in magnitude or changes by less than 1e-6.  The mean is reduced on the device in double
+ * (variant 0: on the host in a float, in index order, as the reference does); one read-back per round,
+ * so it synchronises.  *rounds = rounds run, *last_mean = last mean; either pointer may be NULL. */
+int fsa_iisph_solve_pressure(fsa_solver *s, int maxiter, int *rounds, double *last_mean);
+/* CalcPressureForceKernel alone */
+int fsa_iisph_calc_pressure_force(fsa_solver *s);
+/* IISPHUpdate: CalcPressureForceKernel + IISPHUpdateKernel (vel = v_star + F dt / m, pos += vel dt) */
+int fsa_iisph_update(fsa_solver *s);
+/* SetupIISPH after the scene is uploaded (solver/MultiphaseSPHSolver.cpp:850-860): sort, IISPHFactor,
+ * RigidParticleVolume (EffectiveMass belongs to the multiphase model and InitializeDeformable to the
+ * solids: neither acts on the particle types covered) */
+int fsa_setup_iisph(fsa_solver *s);
+/* nsteps x SolveIISPH without the host read-back of positions */
+int fsa_step_iisph(fsa_solver *s, int nsteps);
 
 /* ---- measurement ------------------------------------------------------ */
 #define FSA_KERNEL_NAME_MAX 32

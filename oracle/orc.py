@@ -18,10 +18,11 @@ TYPE_FLUID, TYPE_CLOTH, TYPE_BOUNDARY, TYPE_EMITTER, TYPE_RIGID = 0, 1, 2, 3, 4
 GRID_UNDEF = 99999999
 
 _VEC3 = ("pos", "vel", "normal", "force", "v_star",
-         "sortedPos", "sortedVel", "sortedNormal", "sortedV_star")
+         "sortedPos", "sortedVel", "sortedNormal", "sortedV_star", "dii", "dijpjl", "pressureForce")
 _VEC4 = ("color", "sortedColor")
 _REAL1 = ("mass", "density", "pressure", "restDensity",
-          "sortedMass", "sortedRestDensity", "sorted_pressure", "DF_factor", "pstiff", "error")
+          "sortedMass", "sortedRestDensity", "sorted_pressure", "DF_factor", "pstiff", "error",
+          "aii", "density_star")
 _INT1 = ("type", "group", "uniqueId", "indexTable", "sortedType", "sortedGroup",
          "sortedUniqueId", "particleHash", "particleIndex")
 _CELL = ("gridCellStart", "gridCellEnd")
@@ -36,6 +37,7 @@ _STATE_FIELDS = (
     "sortedType", "sortedGroup", "sortedUniqueId",
     "particleHash", "particleIndex", "gridCellStart", "gridCellEnd",
     "DF_factor", "pstiff", "error",
+    "dii", "dijpjl", "pressureForce", "aii", "density_star",
 )
 
 
@@ -54,6 +56,7 @@ def _make_types(real):
             ("smoothradius", real), ("kspikydiff", real), ("kernel_cubic", real),
             ("kernel_cubic_gradient", real), ("pressureK", real), ("boundary_visc", real),
             ("acceleration_limit", real), ("boundary_mode", C.c_int), ("kpoly6", real),
+            ("surface_tension", real), ("boundary_friction", real),
         ]
 
     class State(C.Structure):
@@ -94,6 +97,11 @@ class Oracle:
         for name in ("correct_density_error", "correct_divergence_error"):
             self._fn(name, C.c_int, [P, S, C.c_int, self.real, C.POINTER(self.real)])
         self._fn("solve_dfsph", None, [P, S, C.c_int])
+        for name in ("non_pressure_force_multiphase", "iisph_factor", "iisph_predict_density", "iisph_calc_dijpjl",
+                     "iisph_calc_new_pressure", "iisph_calc_pressure_force", "iisph_update"):
+            self._fn(name, None, [P, S])
+        self._fn("iisph_solve_pressure", C.c_int, [P, S, C.c_int, C.c_int, C.POINTER(self.real)])
+        self._fn("solve_iisph", None, [P, S, C.c_int, C.c_int])
 
     def _fn(self, name, restype, argtypes):
         f = getattr(self.lib, self.prefix + name)
@@ -104,7 +112,7 @@ class Oracle:
     # -- parameters -------------------------------------------------
     def make_params(self, spacing, smoothratio, vmin, vmax, *, gravity=(0.0, -10.0, 0.0), dt=0.0004,
                     viscosity=0.05, pressureK=1119.0, boundary_visc=0.0, acceleration_limit=0.0,
-                    boundary_mode=0):
+                    boundary_mode=0, surface_tension=0.0, boundary_friction=0.0):
         p = self.Params()
         r3 = self.real * 3
         self._derive_params(C.byref(p), spacing, smoothratio, r3(*vmin), r3(*vmax))
@@ -115,6 +123,8 @@ class Oracle:
         p.boundary_visc = boundary_visc
         p.acceleration_limit = acceleration_limit
         p.boundary_mode = boundary_mode
+        p.surface_tension = surface_tension
+        p.boundary_friction = boundary_friction
         return p
 
     def set_threads(self, n: int) -> None:
@@ -162,7 +172,8 @@ class OracleState:
         """Copy a scene dict (pos, vel, color, type, group, uniqueId, mass, restDensity, normal) in."""
         n = self.n
         for k in ("pos", "vel", "normal", "color", "mass", "restDensity", "type", "group", "uniqueId",
-                  "v_star", "pressure", "density", "force"):
+                  "v_star", "pressure", "density", "force", "dii", "dijpjl", "pressureForce", "aii",
+                  "density_star"):
             if k in scene:
                 self.a[k][...] = np.asarray(scene[k]).reshape(self.a[k].shape)
         if "uniqueId" not in scene:
@@ -212,3 +223,20 @@ class OracleState:
         return it, e.value
 
     def solve_dfsph(self, p, nsteps=1): self.orc._solve_dfsph(C.byref(p), self._s, int(nsteps))
+
+    # IISPH ------------------------------------------------------------
+    def non_pressure_force_multiphase(self, p): self.orc._non_pressure_force_multiphase(C.byref(p), self._s)
+    def iisph_factor(self, p): self.orc._iisph_factor(C.byref(p), self._s)
+    def iisph_predict_density(self, p): self.orc._iisph_predict_density(C.byref(p), self._s)
+    def iisph_calc_dijpjl(self, p): self.orc._iisph_calc_dijpjl(C.byref(p), self._s)
+    def iisph_calc_new_pressure(self, p): self.orc._iisph_calc_new_pressure(C.byref(p), self._s)
+    def iisph_calc_pressure_force(self, p): self.orc._iisph_calc_pressure_force(C.byref(p), self._s)
+    def iisph_update(self, p): self.orc._iisph_update(C.byref(p), self._s)
+
+    def iisph_solve_pressure(self, p, maxiter=10, mean_in_double=False):
+        e = self.orc.real()
+        rounds = self.orc._iisph_solve_pressure(C.byref(p), self._s, int(maxiter), int(mean_in_double), C.byref(e))
+        return rounds, e.value
+
+    def solve_iisph(self, p, nsteps=1, mean_in_double=False):
+        self.orc._solve_iisph(C.byref(p), self._s, int(nsteps), int(mean_in_double))

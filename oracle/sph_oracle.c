@@ -66,6 +66,7 @@ state_t *ORC_NAME(create)(int n, int num_cells) {
     AI(sortedType); AI(sortedGroup); AI(sortedUniqueId);
     AI(particleHash); AI(particleIndex);
     A1(DF_factor); A1(pstiff); A1(error);
+    A3(dii); A3(dijpjl); A3(pressureForce); A1(aii); A1(density_star);
 #undef A3
 #undef A4
 #undef A1
@@ -85,6 +86,7 @@ void ORC_NAME(destroy)(state_t *s) {
     free(s->sortedType); free(s->sortedGroup); free(s->sortedUniqueId);
     free(s->particleHash); free(s->particleIndex); free(s->gridCellStart); free(s->gridCellEnd);
     free(s->DF_factor); free(s->pstiff); free(s->error);
+    free(s->dii); free(s->dijpjl); free(s->pressureForce); free(s->aii); free(s->density_star);
     free(s);
 }
 
@@ -858,5 +860,387 @@ void ORC_NAME(solve_dfsph)(const params_t *p, state_t *s, int nsteps) {
         ORC_NAME(sort_particles)(p, s);
         ORC_NAME(compute_density_alpha)(p, s);
         ORC_NAME(correct_divergence_error)(p, s, 5, 1, NULL);
+    }
+}
+
+/* ================================================================== */
+/* IISPH step for fluid and rigid particles.                           */
+/* Kernels solver/sph_kernel_impl.cuh:1126-1306 (non-pressure forces)  */
+/* and :3663-4076, launchers solver/sph_solver.cu:300-310, 1388-1457,  */
+/* step MultiphaseSPHSolver::SolveIISPH MultiphaseSPHSolver.cpp:173-188. */
+/* ================================================================== */
+
+/* KernelGradient_Cubic, solver/sph_kernel_impl.cuh:42-54: `q > EPSILON` compares in double, both
+ * polynomial branches are evaluated in double because of their literals. */
+static inline void kernel_gradient_cubic(const params_t *p, R h, R x, R y, R z, R out[3]) {
+    R r = R_SQRT(x * x + y * y + z * z);
+    R q = r / h;
+    if (!(q < 2 && (double)q > ORC_EPSILON)) {
+        out[0] = out[1] = out[2] = 0;
+        return;
+    }
+    R df;
+    if (q >= 1)
+        df = (R)(0.5 * (double)(2 - q) * (double)(2 - q) * (-1));
+    else
+        df = (R)((double)(-2 * q) + 1.5 * (double)q * (double)q);
+    out[0] = x * df * p->kernel_cubic_gradient / r;
+    out[1] = y * df * p->kernel_cubic_gradient / r;
+    out[2] = z * df * p->kernel_cubic_gradient / r;
+}
+
+static inline R dot3(const R *a, const R *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static inline int is_fluid_like(int t) { /* the three `case` labels that share one body */
+    return t == ORC_TYPE_FLUID || t == ORC_TYPE_DEFORMABLE || t == ORC_TYPE_CLOTH;
+}
+
+/* NonPressureForceCell_Multiphase :1126-1262 + NonPressureForceKernel_Multiphase :1264-1306.
+ * pow(float, int) in `fac` and `sr6` is taken as the double overload (C++11 promotion). */
+void ORC_NAME(non_pressure_force_multiphase)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R h = (R)((double)p->smoothradius * 0.5);
+    const R h2 = h * h;
+    const R support_radius = h * 2;
+    const R fac = (R)(32.0f / 3.141593 / pow((double)support_radius, 9.0));
+    const R sr6 = (R)(pow((double)p->smoothradius, 6.0) / 64.0);
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        R *vs = s->v_star + 3 * (size_t)index;
+        const R *veli = s->vel + 3 * (size_t)index;
+        if (s->type[index] == ORC_TYPE_RIGID) {
+            vs[0] = vs[1] = vs[2] = 0;
+            continue;
+        }
+        if (s->type[index] == ORC_TYPE_CLOTH) {
+            for (int a = 0; a < 3; a++) vs[a] = veli[a] + p->gravity[a] * p->dt;
+            continue;
+        }
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R force[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            const R *velj = s->vel + 3 * (size_t)j;
+            R xij[3] = {pos[0] - pos2[0], pos[1] - pos2[1], pos[2] - pos2[2]};
+            R d2 = xij[0] * xij[0] + xij[1] * xij[1] + xij[2] * xij[2];
+            if (d2 >= h2 * 4 || (double)d2 < ORC_EPSILON) continue;
+            R d = R_SQRT(d2);
+            R nablaw[3];
+            kernel_gradient_cubic(p, h, xij[0], xij[1], xij[2], nablaw);
+            R vij[3] = {veli[0] - velj[0], veli[1] - velj[1], veli[2] - velj[2]};
+            R volj = s->mass[j] / s->density[j];
+
+            if (s->type[index] == ORC_TYPE_FLUID && s->type[j] == ORC_TYPE_FLUID) {
+                /* xsph artificial viscosity, :1205-1208 */
+                R w = kernel_cubic(p, h, xij[0], xij[1], xij[2]);
+                R c;
+                if (s->group[index] == 0 || s->group[j] == 0)
+                    c = p->viscosity * volj * (R)(-1) * w / p->dt;
+                else
+                    c = (R)(0.5 * (double)volj * (-1) * (double)w / (double)p->dt);
+                for (int a = 0; a < 3; a++) force[a] += vij[a] * c;
+            }
+            if (s->group[index] == s->group[j]) { /* surface tension, :1214-1232 */
+                R c = support_radius - d;
+                R sf_kernel;
+                if (d < h)
+                    sf_kernel = 2 * c * c * c * d * d2 - sr6;
+                else if (d < support_radius)
+                    sf_kernel = c * c * c * d * d2;
+                else
+                    sf_kernel = 0;
+                sf_kernel *= fac;
+                R tmp = p->surface_tension;
+                if (s->group[index] == 4) tmp *= 10;
+                R k = tmp * volj * sf_kernel / d * (R)(-1);
+                for (int a = 0; a < 3; a++) force[a] += xij[a] * k;
+            }
+            /* :1234-1237 couples two TYPE_DEFORMABLE particles: not covered */
+            if (s->type[j] == ORC_TYPE_RIGID && s->group[j] == 0) { /* wall viscosity and friction, :1239-1259 */
+                R xv = dot3(vij, xij);
+                const R *nj = s->normal + 3 * (size_t)j;
+                R ndv = dot3(nj, vij);
+                R vt[3] = {vij[0] - nj[0] * ndv, vij[1] - nj[1] * ndv, vij[2] - nj[2] * ndv};
+                if (xv < 0) {
+                    R visc = (R)((double)(p->boundary_visc * p->smoothradius) * 88.5 / (double)s->density[index] * 0.25);
+                    R pi = (R)((double)(visc * xv) / ((double)d2 + 0.01 * (double)h2));
+                    R f[3];
+                    for (int a = 0; a < 3; a++) f[a] = nablaw[a] * pi * s->restDensity[index] * s->restDensity[j];
+                    R fdn = dot3(f, nj);
+                    R fn[3] = {nj[0] * fdn, nj[1] * fdn, nj[2] * fdn};
+                    R k = R_SQRT(fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2]) * (R)(-1) * p->boundary_friction;
+                    for (int a = 0; a < 3; a++) force[a] += fn[a];
+                    for (int a = 0; a < 3; a++) force[a] += vt[a] * k;
+                }
+            }
+        })
+        for (int a = 0; a < 3; a++) force[a] += p->gravity[a];
+        for (int a = 0; a < 3; a++) vs[a] = veli[a] + force[a] * p->dt;
+    }
+}
+
+/* mass_j of the IISPH cell functions: mass[i] for a fluid-like neighbour, restDensity[j] *
+ * restDensity[i] for a rigid one; 0 = the neighbour's type takes no part (no `case` for it) */
+static inline int iisph_mass_j(const state_t *s, int i, unsigned j, R *mass_j) {
+    if (is_fluid_like(s->type[j])) {
+        *mass_j = s->mass[i];
+        return 1;
+    }
+    if (s->type[j] == ORC_TYPE_RIGID) {
+        *mass_j = s->restDensity[j] * s->restDensity[i];
+        return 2;
+    }
+    return 0;
+}
+
+/* IISPHFactorCell :3665-3715 + IISPHFactorKernel :3717-3749 */
+void ORC_NAME(iisph_factor)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R density = 0, sum[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            R nablaw[3], mass_j;
+            kernel_gradient_cubic(p, sr / 2, xx, xy, xz, nablaw);
+            if (!iisph_mass_j(s, index, j, &mass_j)) continue;
+            for (int a = 0; a < 3; a++) sum[a] += nablaw[a] * mass_j;
+            density += kernel_cubic(p, sr / 2, xx, xy, xz) * mass_j;
+        })
+        s->density[index] = density;
+        R k = p->dt * p->dt / density / density * (R)(-1);
+        for (int a = 0; a < 3; a++) s->dii[3 * (size_t)index + a] = sum[a] * k;
+    }
+}
+
+/* d_ji of :3784 / :3925: gradW * -1 * mass_j / density_i / density_i * dt * dt * -1, per component */
+static inline void iisph_dji(const params_t *p, const R nablaw[3], R mass_j, R dens_i, R out[3]) {
+    for (int a = 0; a < 3; a++)
+        out[a] = nablaw[a] * (R)(-1) * mass_j / dens_i / dens_i * p->dt * p->dt * (R)(-1);
+}
+
+/* IISPHPredictDensityCell :3751-3805 + IISPHPredictDensityKernel :3807-3833 */
+void ORC_NAME(iisph_predict_density)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        s->pressure[index] /= 2;
+        R density = s->density[index];
+        const R *pos = s->pos + 3 * (size_t)index;
+        const R *vsi = s->v_star + 3 * (size_t)index;
+        const R *dii = s->dii + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R aii = 0;
+        FOR_27_CELLS(g, {
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            const R *vsj = s->v_star + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R vij[3] = {vsi[0] - vsj[0], vsi[1] - vsj[1], vsi[2] - vsj[2]};
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            R nablaw[3], mass_j, dji[3], diff[3];
+            kernel_gradient_cubic(p, sr / 2, xx, xy, xz, nablaw);
+            int kind = iisph_mass_j(s, index, j, &mass_j);
+            if (!kind) continue;
+            if (kind == 1)
+                density += p->dt * mass_j * dot3(vij, nablaw);
+            else
+                density += p->dt * mass_j * dot3(vsi, nablaw);
+            iisph_dji(p, nablaw, mass_j, s->density[index], dji);
+            for (int a = 0; a < 3; a++) diff[a] = dii[a] - dji[a];
+            aii += mass_j * dot3(diff, nablaw);
+        })
+        s->density_star[index] = density;
+        s->aii[index] = aii;
+    }
+}
+
+/* CalcDIJPJLCell :3835-3880 + CalcDIJPJLKernel :3882-3902 */
+void ORC_NAME(iisph_calc_dijpjl)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R acc[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            R nablaw[3];
+            kernel_gradient_cubic(p, sr / 2, xx, xy, xz, nablaw);
+            if (!is_fluid_like(s->type[j])) continue; /* the TYPE_RIGID case is empty */
+            R mass_j = s->mass[index];
+            for (int a = 0; a < 3; a++)
+                acc[a] += nablaw[a] * mass_j / s->density[j] / s->density[j] * s->pressure[j] * (R)(-1);
+        })
+        R k = p->dt * p->dt;
+        for (int a = 0; a < 3; a++) s->dijpjl[3 * (size_t)index + a] = acc[a] * k;
+    }
+}
+
+/* CalcNewPressureCell :3904-3959 + CalcNewPressureKernel :3961-3996.
+ * The reference kernel overwrites pressure[index] while other threads still read pressure[j] of the
+ * same array: what a neighbour sees depends on GPU scheduling.  This restatement takes the
+ * deterministic reading -- every particle sees the pressures of the previous round (Jacobi) -- by
+ * writing the new values to a copy that replaces pressure[] afterwards. */
+void ORC_NAME(iisph_calc_new_pressure)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+    R *newp = (R *)malloc((size_t)(n ? n : 1) * sizeof(R));
+    memcpy(newp, s->pressure, (size_t)n * sizeof(R));
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) {
+            s->error[index] = 0;
+            continue;
+        }
+        const R *pos = s->pos + 3 * (size_t)index;
+        const R *dijpjl_i = s->dijpjl + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R lll = 0;
+        FOR_27_CELLS(g, {
+            if (j >= (unsigned)n) break;
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            R nablaw[3], mass_j;
+            kernel_gradient_cubic(p, sr / 2, xx, xy, xz, nablaw);
+            int kind = iisph_mass_j(s, index, j, &mass_j);
+            if (kind == 1) {
+                R dji[3], lt[3];
+                iisph_dji(p, nablaw, mass_j, s->density[index], dji);
+                const R *dii_j = s->dii + 3 * (size_t)j;
+                const R *dijpjl_j = s->dijpjl + 3 * (size_t)j;
+                for (int a = 0; a < 3; a++)
+                    lt[a] = dijpjl_i[a] - dii_j[a] * s->pressure[j] - dijpjl_j[a] + dji[a] * s->pressure[index];
+                lll += mass_j * dot3(lt, nablaw);
+            } else if (kind == 2) {
+                lll += mass_j * dot3(dijpjl_i, nablaw);
+            }
+        })
+        R prev = s->pressure[index];
+        R density_corr = s->density_star[index] + lll;
+        R aii = s->aii[index];
+        R np;
+        if ((double)(aii < 0 ? -aii : aii) > 1e-8) {
+            np = (R)(0.5 * (double)prev + 0.5 * (double)(s->restDensity[index] - density_corr) / (double)aii);
+            if (np < 0) np = 0;
+        } else {
+            np = 0;
+        }
+        newp[index] = np;
+        density_corr += prev * aii;
+        s->error[index] = density_corr;
+    }
+    memcpy(s->pressure, newp, (size_t)n * sizeof(R));
+    free(newp);
+}
+
+/* IISPHSolvePressure, solver/sph_solver.cu:1409-1443: up to `maxiter` (10 there) rounds, stopped when the
+ * mean of error[] is below 1e-6 in magnitude or moved by less than 1e-6 since the last round. */
+int ORC_NAME(iisph_solve_pressure)(const params_t *p, state_t *s, int maxiter, int mean_in_double, R *last_mean) {
+    R err_sum = 0;
+    int rounds = 0;
+    for (int iter = 0; iter < maxiter; iter++) {
+        ORC_NAME(iisph_calc_dijpjl)(p, s);
+        ORC_NAME(iisph_calc_new_pressure)(p, s);
+        rounds++;
+        R last_err_sum = err_sum;
+        if (mean_in_double) {
+            double acc = 0;
+            for (int i = 0; i < s->n; i++) acc += (double)s->error[i];
+            err_sum = (R)(acc / (double)s->n);
+        } else {
+            err_sum = 0;
+            for (int i = 0; i < s->n; i++) err_sum += s->error[i];
+            err_sum /= s->n;
+        }
+        R a = err_sum < 0 ? -err_sum : err_sum;
+        R b = err_sum - last_err_sum;
+        if (b < 0) b = -b;
+        if ((double)a < 1e-6 || (double)b < 1e-6) break;
+    }
+    if (last_mean) *last_mean = err_sum;
+    return rounds;
+}
+
+/* CalcPressureForceCell :3998-4046 + CalcPressureForceKernel :4048-4065 */
+void ORC_NAME(iisph_calc_pressure_force)(const params_t *p, state_t *s) {
+    const int n = s->n;
+    const R sr = p->smoothradius, sr2 = sr * sr;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        const R *pos = s->pos + 3 * (size_t)index;
+        int g[3];
+        calc_grid_pos(p, pos, g);
+        R pf[3] = {0, 0, 0};
+        FOR_27_CELLS(g, {
+            const R *pos2 = s->pos + 3 * (size_t)j;
+            R xx = pos[0] - pos2[0], xy = pos[1] - pos2[1], xz = pos[2] - pos2[2];
+            R d2 = xx * xx + xy * xy + xz * xz;
+            if (d2 >= sr2) continue;
+            R nablaw[3], mass_j;
+            kernel_gradient_cubic(p, sr / 2, xx, xy, xz, nablaw);
+            int kind = iisph_mass_j(s, index, j, &mass_j);
+            if (kind == 1) {
+                R w = s->pressure[index] / s->density[index] / s->density[index] +
+                      s->pressure[j] / s->density[j] / s->density[j];
+                for (int a = 0; a < 3; a++) pf[a] += nablaw[a] * (R)(-1) * mass_j * mass_j * w;
+            } else if (kind == 2) {
+                R w = s->pressure[index] / s->density[index] / s->density[index];
+                for (int a = 0; a < 3; a++) pf[a] += nablaw[a] * (R)(-1) * s->mass[index] * mass_j * w;
+            }
+        })
+        for (int a = 0; a < 3; a++) s->pressureForce[3 * (size_t)index + a] = pf[a];
+    }
+}
+
+/* IISPHUpdate, solver/sph_solver.cu:1445-1457: CalcPressureForceKernel, then IISPHUpdateKernel :4067-4076 */
+void ORC_NAME(iisph_update)(const params_t *p, state_t *s) {
+    ORC_NAME(iisph_calc_pressure_force)(p, s);
+    const int n = s->n;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        for (int a = 0; a < 3; a++) {
+            size_t k = 3 * (size_t)index + a;
+            s->vel[k] = s->v_star[k] + s->pressureForce[k] * p->dt / s->mass[index];
+            s->pos[k] += s->vel[k] * p->dt;
+        }
+    }
+}
+
+/* MultiphaseSPHSolver::SolveIISPH, MultiphaseSPHSolver.cpp:173-188.  ComputeTension and UpdateSolidState
+ * act on TYPE_DEFORMABLE particles only (solver/sph_kernel_impl.cuh:2913, 3209) and are left out;
+ * Sort (:48-100) is SortParticles for the arrays kept here. */
+void ORC_NAME(solve_iisph)(const params_t *p, state_t *s, int nsteps, int mean_in_double) {
+    for (int k = 0; k < nsteps; k++) {
+        ORC_NAME(non_pressure_force_multiphase)(p, s);
+        ORC_NAME(iisph_predict_density)(p, s);
+        ORC_NAME(iisph_solve_pressure)(p, s, 10, mean_in_double, NULL);
+        ORC_NAME(iisph_update)(p, s);
+        ORC_NAME(sort_particles)(p, s);
+        ORC_NAME(iisph_factor)(p, s);
     }
 }

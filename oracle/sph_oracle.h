@@ -77,6 +77,8 @@ typedef struct ORC_NAME(params) {
     orc_real acceleration_limit;
     int boundary_mode;
     orc_real kpoly6; /* DFSPH density kernel constant, MultiphaseSPHSolver.cpp:464 */
+    orc_real surface_tension;   /* <SurfaceTension>, MultiphaseSPHSolver.cpp:393 */
+    orc_real boundary_friction; /* <Friction>, MultiphaseSPHSolver.cpp:429 */
 } ORC_NAME(params);
 
 /* Hot-path subset of SimData_SPH (solver/sph_solver.cuh:79-190): tight AoS
@@ -94,6 +96,8 @@ typedef struct ORC_NAME(state) {
     int *sortedType, *sortedGroup, *sortedUniqueId;
     int *particleHash, *particleIndex, *gridCellStart, *gridCellEnd;
     orc_real *DF_factor, *pstiff, *error; /* DFSPH, n each (solver/sph_solver.cuh:79-190) */
+    orc_real *dii, *dijpjl, *pressureForce; /* IISPH, n x 3 (solver/sph_solver.cuh:181-188) */
+    orc_real *aii, *density_star;           /* IISPH, n each */
 } ORC_NAME(state);
 
 ORC_NAME(state) *ORC_NAME(create)(int n, int num_cells);
@@ -134,6 +138,25 @@ int ORC_NAME(correct_divergence_error)(const ORC_NAME(params) *p, ORC_NAME(state
                                        orc_real ethres, orc_real *last_error);
 /* SPHSolver::SolveDFSPH without the D2H copy, sph_solver.cpp:108-120 */
 void ORC_NAME(solve_dfsph)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int nsteps);
+
+/* ---- IISPH step, fluid and rigid particles (solver/sph_kernel_impl.cuh:1126-1306, 3663-4076;
+ * launchers solver/sph_solver.cu:300-310, 1388-1457; step MultiphaseSPHSolver.cpp:173-188).
+ * Deformable and cloth particles are outside this restatement: their kernels
+ * (ComputeTensionWithP_Kernel, UpdateSolidStateF_Kernel) do nothing for the types covered. ---- */
+void ORC_NAME(non_pressure_force_multiphase)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(iisph_factor)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(iisph_predict_density)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(iisph_calc_dijpjl)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(iisph_calc_new_pressure)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+/* IISPHSolvePressure: returns the number of rounds run (1..maxiter); *last_mean = last mean of error[].
+ * mean_in_double = 0: the reference's sequential float sum; 1: a double sum rounded once. */
+int ORC_NAME(iisph_solve_pressure)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int maxiter, int mean_in_double,
+                                   orc_real *last_mean);
+void ORC_NAME(iisph_calc_pressure_force)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
+void ORC_NAME(iisph_update)(const ORC_NAME(params) *p, ORC_NAME(state) *s); /* both kernels of IISPHUpdate */
+/* SolveIISPH without the D2H copy; the state must have been prepared as SetupIISPH does
+ * (MultiphaseSPHSolver.cpp:850-860): sorted, iisph_factor and rigid_particle_volume run once. */
+void ORC_NAME(solve_iisph)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int nsteps, int mean_in_double);
 
 #ifdef __cplusplus
 }

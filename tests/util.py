@@ -10,7 +10,9 @@ def oracle_pair(orc, scene, **over):
     P.update(over)
     p = orc.make_params(P["spacing"], P["smoothratio"], P["vmin"], P["vmax"], gravity=P["gravity"], dt=P["dt"],
                         viscosity=P["viscosity"], pressureK=P["pressureK"], boundary_visc=P["boundary_visc"],
-                        acceleration_limit=P["acceleration_limit"], boundary_mode=P["boundary_mode"])
+                        acceleration_limit=P["acceleration_limit"], boundary_mode=P["boundary_mode"],
+                        surface_tension=P.get("surface_tension", 0.0),
+                        boundary_friction=P.get("boundary_friction", 0.0))
     nc = p.gridres[0] * p.gridres[1] * p.gridres[2]
     st = orc.new_state(len(scene["pos"]), nc)
     sc = dict(scene)
