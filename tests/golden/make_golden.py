@@ -6,7 +6,8 @@
 The reference ships no golden vectors for this path and cannot be built here, so these files pin the
 ORACLE (and, through the GPU tests, the HIP path) against silent change; they are not outputs of the
 reference.  One file per precision: the inputs of a small noisy dam break with wall particles and the
-outputs of every stage of one step, plus the positions after five whole steps.
+outputs of every stage of one step, plus the positions after five whole steps; and, in iisph_tank_*.npz,
+the same for the IISPH step on a small tank whose wall uses the viscosity / friction branch.
 """
 import json
 import os
@@ -68,6 +69,51 @@ def generate(precision):
     print(path, os.path.getsize(path), "bytes")
 
 
+def iisph_scene():
+    sc = scenes.iisph_tank(7, 9, 6, wall_group=0, fluid_groups=(1, 2), boundary_visc=0.1, boundary_friction=1.0)
+    return scenes.jittered(sc, seed=777, pos_jitter=0.15, vel_scale=0.4, fluid_only=True)
+
+
+def generate_iisph(precision):
+    orc = Oracle(precision)
+    orc.set_threads(1)
+    sc = iisph_scene()
+    p, st = oracle_pair(orc, sc)
+    out = {"params_json": np.frombuffer(json.dumps(sc["params"]).encode(), dtype=np.uint8)}
+    for k in ("pos", "vel", "type", "mass", "restDensity", "color", "normal", "group", "uniqueId"):
+        out["in_" + k] = np.asarray(sc[k])
+    st.sort_particles(p)
+    st.iisph_factor(p)
+    st.rigid_particle_volume(p)
+    out["sorted_uniqueId"] = st["uniqueId"].copy()
+    out["density0"] = st["density"].copy()
+    out["dii0"] = st["dii"].copy()
+    out["restDensity0"] = st["restDensity"].copy()
+    st.non_pressure_force_multiphase(p)
+    out["v_star"] = st["v_star"].copy()
+    st.iisph_predict_density(p)
+    out["aii"] = st["aii"].copy()
+    out["density_star"] = st["density_star"].copy()
+    rounds, mean = st.iisph_solve_pressure(p, 10)
+    out["rounds"] = np.int32(rounds)
+    out["pressure"] = st["pressure"].copy()
+    out["error"] = st["error"].copy()
+    st.iisph_update(p)
+    out["pressureForce"] = st["pressureForce"].copy()
+    out["pos_after"] = st["pos"].copy()
+    out["vel_after"] = st["vel"].copy()
+    st.sort_particles(p)
+    st.iisph_factor(p)
+    st.solve_iisph(p, 2)
+    out["pos_step3_by_id"] = st["pos"][np.argsort(st["uniqueId"])].copy()
+    st.close()
+    path = os.path.join(HERE, f"iisph_tank_{precision}.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     generate("f32")
     generate("f64")
+    generate_iisph("f32")
+    generate_iisph("f64")
