@@ -62,6 +62,7 @@ void MultiphaseSPHSolver::ParseParam(const char *xmlpath) {
     hParam.pressureK = reader.GetFloat("PressureK");
     reader.GetFloatN(densArr, maxtypenum, "DensityArray");
     reader.GetFloatN(viscArr, maxtypenum, "ViscosityArray");
+    hParam.surface_tension = reader.GetFloat("SurfaceTension");
     hParam.acceleration_limit = reader.GetFloat("AccelerationLimit");
     // this build's optional tags
     if (reader.GetText("GridMin")) lo = reader.GetFloat3("GridMin");
@@ -72,7 +73,13 @@ void MultiphaseSPHSolver::ParseParam(const char *xmlpath) {
     if (reader.GetText("WallType")) wall_type = reader.GetInt("WallType");
     wall_rest_density = reader.GetFloat("WallRestDensity");
     hParam.boundary_mode = reader.GetInt("BoundaryMode");
-    if (const char *m = reader.GetText("RunMode")) run_mode = std::strcmp(m, "SPH") == 0 ? SPH : IISPH;
+    if (const char *m = reader.GetText("RunMode")) {
+        const std::string mode(m);
+        // surrounding blanks of the tag text do not count
+        const size_t a = mode.find_first_not_of(" \t\r\n"), b = mode.find_last_not_of(" \t\r\n");
+        const std::string word = a == std::string::npos ? "" : mode.substr(a, b - a + 1);
+        run_mode = word == "SPH" ? SPH : word == "DFSPH" ? DFSPH : word == "IISPH" ? IISPH : -1;
+    }
 
     // smoothradius, dx, gridres and the kernel constants exactly as LoadParam evaluates them in float
     const double vmin[3] = {lo.x, lo.y, lo.z}, vmax[3] = {hi.x, hi.y, hi.z};
@@ -82,6 +89,7 @@ void MultiphaseSPHSolver::ParseParam(const char *xmlpath) {
 
     reader.Use(bound);
     hParam.boundary_visc = reader.GetFloat("Viscosity");
+    hParam.boundary_friction = reader.GetFloat("Friction");
 }
 
 // LoadParam, solver/MultiphaseSPHSolver.cpp:435-473
@@ -226,23 +234,52 @@ void MultiphaseSPHSolver::SetupDFSPH() {
     }
 }
 
+// SetupIISPH, solver/MultiphaseSPHSolver.cpp:850-860.  Two of its calls have nothing to do here:
+// EffectiveMass recomputes mass and rest density from the volume fractions, which AddMultiphaseFluidVolumes
+// has already set to the same values for a fluid that does not change its mix, and InitializeDeformable
+// acts on TYPE_DEFORMABLE particles only.
+void MultiphaseSPHSolver::SetupIISPH() {
+    SetupFluidScene();
+    run_mode = IISPH;
+    if (numParticles > 0) {
+        check(fsa_setup_iisph(device), "SetupIISPH");
+        CopyPosColorFromDevice();
+    }
+}
+
+// The reference's Setup() is `SetupIISPH();` (solver/MultiphaseSPHSolver.cpp:862-866).  Here the step is
+// picked by FSA_RUN_MODE, else by the scene's <RunMode> tag, else it is the WCSPH step.
 void MultiphaseSPHSolver::Setup() {
-    const char *mode = std::getenv("FSA_RUN_MODE");
-    if (mode && std::strcmp(mode, "DFSPH") == 0) {
+    int want = SPH;
+    if (const char *mode = std::getenv("FSA_RUN_MODE")) {
+        if (std::strcmp(mode, "SPH") == 0) want = SPH;
+        else if (std::strcmp(mode, "DFSPH") == 0) want = DFSPH;
+        else if (std::strcmp(mode, "IISPH") == 0) want = IISPH;
+        else {
+            std::fprintf(stderr, "FSA_RUN_MODE=%s: this build has the SPH (WCSPH), DFSPH and IISPH steps\n", mode);
+            std::exit(EXIT_FAILURE);
+        }
+    } else {
+        // the tag is only known once the scene file is read: peek at it
+        run_mode = SPH;
+        LoadParam(config_path("sph_scene.xml"));
+        if (run_mode < 0) {
+            std::fprintf(stderr, "<RunMode> of the scene asks for a step this build does not have\n");
+            std::exit(EXIT_FAILURE);
+        }
+        want = run_mode;
+    }
+    if (want == DFSPH) {
         SetupDFSPH();
         return;
     }
-    if (mode && std::strcmp(mode, "SPH") != 0) {
-        std::fprintf(stderr, "FSA_RUN_MODE=%s: this build has the SPH (WCSPH) and DFSPH steps\n", mode);
-        std::exit(EXIT_FAILURE);
+    if (want == IISPH) {
+        SetupIISPH();
+        return;
     }
     SetupSPH();
     // resume from a text checkpoint written by key 'b' (DumpSimulationDataText)
     if (const char *resume = std::getenv("FSA_RESUME")) LoadSimulationDataText(resume);
-    if (run_mode != SPH) {
-        std::fprintf(stderr, "<RunMode> of the scene asks for a step this build does not have\n");
-        std::exit(EXIT_FAILURE);
-    }
 }
 
 // Text checkpoint of solver/MultiphaseSPHSolver.cpp:219-247: the single-phase line plus the volume fractions.

@@ -3,8 +3,8 @@
 // Step() per frame.
 //
 // The reference's Setup() always selects its IISPH step; which step runs here is chosen at run time:
-// environment variable FSA_RUN_MODE ("SPH" = WCSPH, the default, or "DFSPH"), or a
-// <RunMode> tag in the scene.  FSA_RESUME=<file> continues from a text checkpoint (key 'b').  Two more optional scene tags exist for the WCSPH step, which has no wall
+// environment variable FSA_RUN_MODE ("SPH" = WCSPH, the default, "DFSPH" or "IISPH"), or a
+// <RunMode> tag in the scene with one of those words.  FSA_RESUME=<file> continues from a text checkpoint (key 'b').  Two more optional scene tags exist for the WCSPH step, which has no wall
 // response for TYPE_RIGID particles: <WallType> (particle type given to the boundary file's particles,
 // default 4 = TYPE_RIGID as LoadPO assigns), <WallRestDensity>, and <BoundaryMode> (0 verbatim
 // integration, 1 legacy clamp to the grid box).  <GridMin> / <GridMax> give a scene its own grid box
@@ -44,6 +44,7 @@ public:
     void ClearParticles();
     void SetupSPH();
     void SetupDFSPH();
+    void SetupIISPH();
 
     void DumpSimulationDataText() override;
     void LoadSimulationDataText(const char *filepath);

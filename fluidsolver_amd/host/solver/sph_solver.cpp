@@ -100,6 +100,17 @@ void SPHSolver::SolveDFSPH() {
     check(fsa_correct_divergence_error(device, 5, 1, nullptr, nullptr), "correctDivergenceError");
 }
 
+// SolveIISPH, solver/MultiphaseSPHSolver.cpp:173-188; ComputeTension and UpdateSolidState act on
+// TYPE_DEFORMABLE particles only and have no counterpart here
+void SPHSolver::SolveIISPH() {
+    check(fsa_non_pressure_force_multiphase(device), "NonPressureForce_Multiphase");
+    check(fsa_iisph_predict_density(device), "IISPHPredictDensity");
+    check(fsa_iisph_solve_pressure(device, 10, nullptr, nullptr), "IISPHSolvePressure");
+    check(fsa_iisph_update(device), "IISPHUpdate");
+    SortParticles();
+    check(fsa_iisph_factor(device), "IISPHFactor");
+}
+
 // Step, solver/sph_solver.cpp:129-142 and solver/MultiphaseSPHSolver.cpp:199-217
 void SPHSolver::Step() {
     if (numParticles > 0) {
@@ -110,8 +121,11 @@ void SPHSolver::Step() {
         case DFSPH:
             SolveDFSPH();
             break;
+        case IISPH:
+            SolveIISPH();
+            break;
         default:
-            std::fprintf(stderr, "run mode %d is not available in this build (SPH and DFSPH are)\n", run_mode);
+            std::fprintf(stderr, "run mode %d is not available in this build (SPH, DFSPH and IISPH are)\n", run_mode);
             std::exit(EXIT_FAILURE);
         }
     }

@@ -72,6 +72,7 @@ public:
     void SortParticles();
     void SolveSPH();
     void SolveDFSPH();
+    void SolveIISPH();
 
     int AddDefaultParticle();
 

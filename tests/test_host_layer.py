@@ -211,3 +211,31 @@ def test_headless_program_dfsph_mode(tmp_path):
     want, _ = s.readback_pos_color()
     assert pos.tobytes() == want.tobytes()
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_headless_program_iisph_mode_on_the_shipped_scene(tmp_path):
+    """the step the reference's Setup() selects, on the scene it ships: fluid block of scene 2 in the
+    TYPE_RIGID box of 'big box.xml'"""
+    from fluidsolver_amd import capi
+    frames = 6
+    final = tmp_path / "final.bin"
+    e = env_for(2)
+    e["FSA_RUN_MODE"] = "IISPH"
+    subprocess.check_call([os.path.join(HOST, "bin", "particle_solver"), "--frames", str(frames), "--save-final",
+                           str(final)], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    pos, _ = read_final(final)
+    sc = scenes.reference_scene()
+    sc["params"] = dict(sc["params"], surface_tension=100.0)  # <SurfaceTension> of scene 2
+    p = capi.make_params(capi.PRECISION_F32, **sc["params"])
+    s = capi.Solver(p, len(sc["pos"]))
+    s.upload(sc)
+    s.setup_iisph()
+    s.step_iisph(frames)
+    want, _ = s.readback_pos_color()
+    assert np.isfinite(want).all()
+    assert pos.tobytes() == want.tobytes()
+    fluid = s.get("type") == 0
+    assert s.get("density")[fluid].max() < 1.05 * 750.0  # the block's rest density
+    s.close()
