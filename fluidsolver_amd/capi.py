@@ -37,6 +37,11 @@ EXPORTS = (
     "fsa_non_pressure_force_multiphase", "fsa_iisph_factor", "fsa_iisph_predict_density", "fsa_iisph_calc_dijpjl",
     "fsa_iisph_calc_new_pressure", "fsa_iisph_solve_pressure", "fsa_iisph_calc_pressure_force", "fsa_iisph_update",
     "fsa_setup_iisph", "fsa_step_iisph",
+    "fsa_grid_create", "fsa_grid_destroy", "fsa_grid_sizes", "fsa_grid_synchronize", "fsa_grid_get_field",
+    "fsa_grid_set_field", "fsa_grid_set_particles", "fsa_grid_get_particles", "fsa_grid_advect",
+    "fsa_grid_advect_particles", "fsa_grid_body_force", "fsa_grid_testcase", "fsa_grid_div_velocity",
+    "fsa_grid_make_rhs", "fsa_grid_solve", "fsa_grid_update_u", "fsa_grid_mvproduct", "fsa_grid_dotproduct",
+    "fsa_grid_step",
 )
 
 
@@ -140,6 +145,19 @@ def load() -> C.CDLL:
         "fsa_iisph_calc_dijpjl": [H], "fsa_iisph_calc_new_pressure": [H], "fsa_iisph_calc_pressure_force": [H],
         "fsa_iisph_update": [H], "fsa_setup_iisph": [H], "fsa_step_iisph": [H, C.c_int],
         "fsa_iisph_solve_pressure": [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)],
+        "fsa_grid_create": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                            C.POINTER(C.c_void_p)],
+        "fsa_grid_destroy": [H], "fsa_grid_sizes": [H, C.POINTER(C.c_int), C.POINTER(C.c_double)],
+        "fsa_grid_synchronize": [H], "fsa_grid_get_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
+        "fsa_grid_set_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
+        "fsa_grid_set_particles": [H, C.c_int, C.c_void_p],
+        "fsa_grid_get_particles": [H, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
+        "fsa_grid_advect": [H], "fsa_grid_advect_particles": [H], "fsa_grid_body_force": [H], "fsa_grid_testcase": [H],
+        "fsa_grid_div_velocity": [H, C.POINTER(C.c_double)], "fsa_grid_make_rhs": [H],
+        "fsa_grid_solve": [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)], "fsa_grid_update_u": [H],
+        "fsa_grid_mvproduct": [H, C.c_char_p, C.c_char_p],
+        "fsa_grid_dotproduct": [H, C.c_char_p, C.c_char_p, C.POINTER(C.c_double)],
+        "fsa_grid_step": [H, C.c_int, C.c_int],
     }
     for name, args in protos.items():
         f = getattr(lib, name)
@@ -385,3 +403,90 @@ class Solver:
         cnt = C.c_int()
         check(self.lib.fsa_timing_read(self._h, arr, cap, C.byref(cnt)))
         return {arr[k].name.decode(): (arr[k].launches, arr[k].total_ms) for k in range(min(cnt.value, cap))}
+
+
+class GridSolver:
+    """Thin object wrapper over one fsa_grid handle (the Eulerian grid solver)."""
+
+    FACE = ("u", "v", "w", "uadv", "vadv", "wadv")
+    CELL = ("p", "divU", "b", "Aq", "r", "q")
+
+    def __init__(self, dim, padding=1, h=0.02, dt=0.001, rho=1.0, precision=PRECISION_F32, device: int = 0):
+        self.lib = load()
+        self.precision = precision
+        self.dtype = np.float32 if precision == PRECISION_F32 else np.float64
+        self.dim = tuple(int(d) for d in dim)
+        self.padding = int(padding)
+        h_ = C.c_void_p()
+        check(self.lib.fsa_grid_create((C.c_int * 3)(*self.dim), self.padding, float(h), float(dt), float(rho),
+                                       precision, device, C.byref(h_)))
+        self._h = h_
+        sizes, xmin = (C.c_int * 4)(), (C.c_double * 3)()
+        check(self.lib.fsa_grid_sizes(self._h, sizes, xmin))
+        self.sizes = tuple(sizes)
+        self.xmin = np.array(xmin[:])
+        nx, ny, nz = self.dim
+        pd = self.padding
+        self.shapes = {"u": (nz + 2 * pd, ny + 2 * pd, nx + 2 * pd + 1), "v": (nz + 2 * pd, ny + 2 * pd + 1, nx + 2 * pd),
+                       "w": (nz + 2 * pd + 1, ny + 2 * pd, nx + 2 * pd)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fsa_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shape(self, name):
+        return self.shapes[name[0]] if name in self.FACE else (self.dim[2], self.dim[1], self.dim[0])
+
+    def get(self, name: str) -> np.ndarray:
+        out = np.empty(self.shape(name), self.dtype)
+        check(self.lib.fsa_grid_get_field(self._h, name.encode(), _ptr(out), out.nbytes))
+        return out
+
+    def set(self, name: str, value) -> None:
+        a = np.ascontiguousarray(value, self.dtype)
+        if a.shape != self.shape(name):
+            raise ValueError(f"field {name}: shape {a.shape}, expected {self.shape(name)}")
+        check(self.lib.fsa_grid_set_field(self._h, name.encode(), _ptr(a), a.nbytes))
+
+    def set_particles(self, pos):
+        a = np.ascontiguousarray(pos, self.dtype).reshape(-1, 3)
+        check(self.lib.fsa_grid_set_particles(self._h, len(a), _ptr(a)))
+
+    def get_particles(self):
+        n = C.c_int()
+        check(self.lib.fsa_grid_get_particles(self._h, None, None, C.byref(n)))
+        pos, col = np.empty((n.value, 3), self.dtype), np.empty((n.value, 4), self.dtype)
+        check(self.lib.fsa_grid_get_particles(self._h, _ptr(pos), _ptr(col), C.byref(n)))
+        return pos, col
+
+    def advect(self): check(self.lib.fsa_grid_advect(self._h))
+    def advect_particles(self): check(self.lib.fsa_grid_advect_particles(self._h))
+    def body_force(self): check(self.lib.fsa_grid_body_force(self._h))
+    def testcase(self): check(self.lib.fsa_grid_testcase(self._h))
+    def make_rhs(self): check(self.lib.fsa_grid_make_rhs(self._h))
+    def update_u(self): check(self.lib.fsa_grid_update_u(self._h))
+    def synchronize(self): check(self.lib.fsa_grid_synchronize(self._h))
+    def step(self, nsteps=1, maxiter=-1): check(self.lib.fsa_grid_step(self._h, int(nsteps), int(maxiter)))
+    def mvproduct(self, src, dst): check(self.lib.fsa_grid_mvproduct(self._h, src.encode(), dst.encode()))
+
+    def div_velocity(self) -> float:
+        s = C.c_double()
+        check(self.lib.fsa_grid_div_velocity(self._h, C.byref(s)))
+        return s.value
+
+    def dotproduct(self, a, b) -> float:
+        s = C.c_double()
+        check(self.lib.fsa_grid_dotproduct(self._h, a.encode(), b.encode(), C.byref(s)))
+        return s.value
+
+    def solve(self, maxiter=-1):
+        it, r = C.c_int(), C.c_double()
+        check(self.lib.fsa_grid_solve(self._h, int(maxiter), C.byref(it), C.byref(r)))
+        return it.value, r.value

@@ -1,0 +1,931 @@
+// Eulerian grid solver for gfx950: semi-Lagrangian advection on a staggered grid, gravity, pressure
+// projection by conjugate gradients, tracer particles.  Replaces the CPU loops of the reference's
+// GridSolver (solver/grid_solver.cpp under /root/reference/particle_solver; every kernel cites the lines
+// it restates) and is reached through the fsa_grid_* entries of include/fluidsolver_amd.h.
+//
+// Layout: face arrays are padded exactly as Grid::uId / vId / wId index them (solver/grid_solver.h:39-49),
+// x fastest, so a wavefront reads 64 consecutive faces; cell arrays are dim.x * dim.y * dim.z, x fastest.
+// Arithmetic follows the reference text operation for operation (explicit casts where its double
+// literals promote a float expression); the only exception is the three sums of the CG loop (two dot
+// products and the mean residual), which the reference accumulates in one float in index order and this
+// file reduces in double over a fixed tree, the same for every run.
+//
+// The CG loop runs without host round trips: its scalars (alpha, beta, the stop decision) live in device
+// memory, every kernel of a round returns at once when the loop has ended, and the host launches rounds in
+// batches and looks at the state between batches.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "fsa_solver.h"
+
+namespace fsa {
+
+constexpr int kPartials = 2048;  // block partial sums per reduction (grid-stride loops above that)
+
+template <typename T> struct GridDev {
+    int nx, ny, nz, pad;
+    int xlen, ylen, zlen, ulen, vlen, wlen;
+    int dimSize;
+    T xmin[3];
+    T h, dt, rho;
+};
+
+// device-resident state of the CG loop
+struct CgState {
+    double rr, qAq, rr_new, rabs_sum;  // raw sums
+    double alpha, beta, rabs;          // as the loop uses them (rounded to the solver's precision)
+    int finished;                      // 1: loop ended (break at the top of a round)
+    int pending;                       // 1: loop ends after this round's direction update
+    int iter;                          // the reference's `iter`
+    int maxiter;                       // < 0: none
+    int rounds;                        // rounds completed (diagnostic)
+};
+
+struct GridSolver {
+    int precision = FSA_PRECISION_F32;
+    int device = 0;
+    GridDev<float> gf{};
+    GridDev<double> gd{};
+    int uSize = 0, vSize = 0, wSize = 0, dimSize = 0;
+    void *u = nullptr, *v = nullptr, *w = nullptr, *uadv = nullptr, *vadv = nullptr, *wadv = nullptr;
+    void *p = nullptr, *divU = nullptr, *b = nullptr, *Aq = nullptr, *r = nullptr, *q = nullptr;
+    double *partials = nullptr;  // 4 * kPartials
+    CgState *cg = nullptr;
+    double *divsum = nullptr;
+    void *ppos = nullptr, *pcolor = nullptr;
+    int n_particles = 0, particle_cap = 0;
+    int frame = 0;
+    hipStream_t stream = nullptr;
+    size_t real_size() const { return precision == FSA_PRECISION_F64 ? sizeof(double) : sizeof(float); }
+};
+
+__device__ __forceinline__ float g_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double g_floor(double x) { return floor(x); }
+__device__ __forceinline__ float g_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double g_abs(double x) { return fabs(x); }
+
+// Grid::cellId / uId / vId / wId, solver/grid_solver.h:36-49
+template <typename T> __device__ __forceinline__ int cell_id(const GridDev<T> &G, int x, int y, int z) {
+    return (z * G.ny + y) * G.nx + x;
+}
+template <typename T> __device__ __forceinline__ int u_id(const GridDev<T> &G, int x, int y, int z) {
+    return ((z + G.pad) * G.ylen + y + G.pad) * G.ulen + x + G.pad;
+}
+template <typename T> __device__ __forceinline__ int v_id(const GridDev<T> &G, int x, int y, int z) {
+    return ((z + G.pad) * G.vlen + y + G.pad) * G.xlen + x + G.pad;
+}
+template <typename T> __device__ __forceinline__ int w_id(const GridDev<T> &G, int x, int y, int z) {
+    return ((z + G.pad) * G.ylen + y + G.pad) * G.xlen + x + G.pad;
+}
+
+// ---- sampling (sampleU :301-350, sampleV :352-401, sampleW :403-452) -------------------------------
+// COMP = 0, 1, 2 selects the component; the component's own axis is sampled on faces, the other two on
+// cell centres shifted by half a cell.
+constexpr double kSampleEps = 0.000000001;  // the EPSILON in force from :299 on
+
+template <typename T, int COMP>
+__device__ __forceinline__ T sample_component(const GridDev<T> &G, const T *__restrict__ f, T px, T py, T pz) {
+    const T p[3] = {px, py, pz};
+    const int dim[3] = {G.nx, G.ny, G.nz};
+    T x[3];
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        x[a] = (p[a] - G.xmin[a]) / G.h;
+        c[a] = (int)g_floor(x[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if ((double)(x[a] - (T)c[a]) < kSampleEps && x[a] == (T)dim[a]) c[a] -= 1;
+        if ((double)x[a] > -kSampleEps && x[a] == (T)-1) c[a] += 1;
+    }
+    if (c[0] < 0 || c[0] > G.nx - 1 || c[1] < 0 || c[1] > G.ny - 1 || c[2] < 0 || c[2] > G.nz - 1) return 0;
+    T wt[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (a == COMP) {
+            wt[a] = (p[a] - (G.xmin[a] + (T)c[a] * G.h)) / G.h;
+        } else {
+            if ((double)(x[a] - (T)c[a]) < 0.5) c[a]--;
+            wt[a] = (T)(((double)p[a] - ((double)G.xmin[a] + ((double)c[a] + 0.5) * (double)G.h)) / (double)G.h);
+        }
+    }
+    auto at = [&](int dx, int dy, int dz) -> T {
+        const int X = c[0] + dx, Y = c[1] + dy, Z = c[2] + dz;
+        return f[COMP == 0 ? u_id(G, X, Y, Z) : COMP == 1 ? v_id(G, X, Y, Z) : w_id(G, X, Y, Z)];
+    };
+    const T w1 = wt[0], w2 = wt[1], w3 = wt[2];
+    return (1 - w1) * ((1 - w2) * ((1 - w3) * at(0, 0, 0) + w3 * at(0, 0, 1)) +
+                       w2 * ((1 - w3) * at(0, 1, 0) + w3 * at(0, 1, 1))) +
+           w1 * ((1 - w2) * ((1 - w3) * at(1, 0, 0) + w3 * at(1, 0, 1)) +
+                 w2 * ((1 - w3) * at(1, 1, 0) + w3 * at(1, 1, 1)));
+}
+
+template <typename T> __device__ __forceinline__ T at_face(const GridDev<T> &G, int a, int i) {
+    return G.xmin[a] + G.h * (T)i;
+}
+template <typename T> __device__ __forceinline__ T at_centre(const GridDev<T> &G, int a, int i) {
+    return (T)((double)G.xmin[a] + (double)G.h * ((double)i + 0.5));
+}
+template <typename T> __device__ __forceinline__ T quarter(T a, T b, T c, T d) {
+    return (T)((double)(a + b + c + d) * 0.25);
+}
+
+// advect :456-565, one thread per face of component COMP.  u is traced back one step along x only
+// (:485-489); v and w take a midpoint step (:526-534, :552-560).
+template <typename T, int COMP>
+__global__ __launch_bounds__(kBlock) void grid_advect_kernel(GridDev<T> G, const T *__restrict__ u,
+                                                             const T *__restrict__ v, const T *__restrict__ w,
+                                                             T *__restrict__ out) {
+    const int ex = G.nx + (COMP == 0), ey = G.ny + (COMP == 1), ez = G.nz + (COMP == 2);
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)ex * ey * ez) return;
+    const int i = (int)(t % ex), j = (int)((t / ex) % ey), k = (int)(t / ((long long)ex * ey));
+    T vel[3], xt[3];
+    if (COMP == 0) {
+        vel[0] = u[u_id(G, i, j, k)];
+        vel[1] = 0;
+        vel[2] = 0;
+        xt[0] = at_face(G, 0, i);
+        xt[1] = at_centre(G, 1, j);
+        xt[2] = at_centre(G, 2, k);
+        const T s = (T)-1;
+        out[u_id(G, i, j, k)] = sample_component<T, 0>(G, u, xt[0] + vel[0] * G.dt * s, xt[1] + vel[1] * G.dt * s,
+                                                       xt[2] + vel[2] * G.dt * s);
+        return;
+    }
+    if (COMP == 1) {
+        vel[0] = quarter(u[u_id(G, i, j, k)], u[u_id(G, i + 1, j, k)], u[u_id(G, i, j - 1, k)],
+                         u[u_id(G, i + 1, j - 1, k)]);
+        vel[1] = v[v_id(G, i, j, k)];
+        vel[2] = quarter(w[w_id(G, i, j, k)], w[w_id(G, i, j, k + 1)], w[w_id(G, i, j - 1, k)],
+                         w[w_id(G, i, j - 1, k + 1)]);
+        xt[0] = at_centre(G, 0, i);
+        xt[1] = at_face(G, 1, j);
+        xt[2] = at_centre(G, 2, k);
+    } else {
+        vel[0] = quarter(u[u_id(G, i, j, k)], u[u_id(G, i, j, k - 1)], u[u_id(G, i + 1, j, k)],
+                         u[u_id(G, i + 1, j, k - 1)]);
+        vel[1] = quarter(v[v_id(G, i, j, k)], v[v_id(G, i, j, k - 1)], v[v_id(G, i, j + 1, k)],
+                         v[v_id(G, i, j + 1, k - 1)]);
+        vel[2] = w[w_id(G, i, j, k)];
+        xt[0] = at_centre(G, 0, i);
+        xt[1] = at_centre(G, 1, j);
+        xt[2] = at_face(G, 2, k);
+    }
+    const T half = (T)-0.5, full = (T)-1;
+    const T mx = xt[0] + vel[0] * G.dt * half, my = xt[1] + vel[1] * G.dt * half, mz = xt[2] + vel[2] * G.dt * half;
+    const T su = sample_component<T, 0>(G, u, mx, my, mz);
+    const T sv = sample_component<T, 1>(G, v, mx, my, mz);
+    const T sw = sample_component<T, 2>(G, w, mx, my, mz);
+    const T bx = xt[0] + su * G.dt * full, by = xt[1] + sv * G.dt * full, bz = xt[2] + sw * G.dt * full;
+    if (COMP == 1)
+        out[v_id(G, i, j, k)] = sample_component<T, 1>(G, v, bx, by, bz);
+    else
+        out[w_id(G, i, j, k)] = sample_component<T, 2>(G, w, bx, by, bz);
+}
+
+// advectParticles :639-651
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_advect_particles_kernel(GridDev<T> G, int n, const T *__restrict__ u,
+                                                                       const T *__restrict__ v,
+                                                                       const T *__restrict__ w, T *__restrict__ pos,
+                                                                       T *__restrict__ color) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    T x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+    const T vx = sample_component<T, 0>(G, u, x, y, z);
+    const T vy = sample_component<T, 1>(G, v, x, y, z);
+    const T vz = sample_component<T, 2>(G, w, x, y, z);
+    pos[3 * (size_t)i] = x + vx * G.dt;
+    pos[3 * (size_t)i + 1] = y + vy * G.dt;
+    pos[3 * (size_t)i + 2] = z + vz * G.dt;
+    const T l = 1;
+    color[4 * (size_t)i] = (T)((double)g_abs(vx) / 0.01);
+    color[4 * (size_t)i + 1] = 0;
+    color[4 * (size_t)i + 2] = g_abs(vz) / l;
+}
+
+// bodyForce :579-588
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_body_force_kernel(GridDev<T> G, T *__restrict__ v) {
+    const int ey = G.ny + 1;
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)G.nx * ey * G.nz) return;
+    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % ey), k = (int)(t / ((long long)G.nx * ey));
+    v[v_id(G, i, j, k)] += 10 * G.dt;
+}
+
+// testcase :590-606
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_testcase_kernel(GridDev<T> G, T *__restrict__ u, T *__restrict__ v,
+                                                               T *__restrict__ w) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)G.dimSize) return;
+    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((long long)G.nx * G.ny));
+    u[u_id(G, i, j, k)] = (T)(i * 2);
+    v[v_id(G, i, j, k)] = (T)(j * 3);
+    w[w_id(G, i, j, k)] = (T)(k * 4);
+    if (i == G.nx - 1) u[u_id(G, i + 1, j, k)] = (T)((i + 1) * 2);
+    if (j == G.ny - 1) v[v_id(G, i, j + 1, k)] = (T)((j + 1) * 3);
+    if (k == G.nz - 1) w[w_id(G, i, j, k + 1)] = (T)((k + 1) * 4);
+}
+
+// Grid-stride walk over the cells that keeps (i, j, k) by carrying instead of dividing per element.
+template <typename T> struct CellWalk {
+    unsigned t, stride;
+    int i, j, k, di, dj, dk;
+    __device__ __forceinline__ explicit CellWalk(const GridDev<T> &G) {
+        t = blockIdx.x * kBlock + threadIdx.x;
+        stride = gridDim.x * kBlock;
+        const unsigned plane = (unsigned)G.nx * (unsigned)G.ny;
+        i = (int)(t % (unsigned)G.nx);
+        j = (int)((t / (unsigned)G.nx) % (unsigned)G.ny);
+        k = (int)(t / plane);
+        di = (int)(stride % (unsigned)G.nx);
+        dj = (int)((stride / (unsigned)G.nx) % (unsigned)G.ny);
+        dk = (int)(stride / plane);
+    }
+    __device__ __forceinline__ bool valid(const GridDev<T> &G) const { return t < (unsigned)G.dimSize; }
+    __device__ __forceinline__ void next(const GridDev<T> &G) {
+        t += stride;
+        i += di;
+        int c = i >= G.nx ? 1 : 0;
+        i -= c ? G.nx : 0;
+        j += dj + c;
+        c = j >= G.ny ? 1 : 0;
+        j -= c ? G.ny : 0;
+        k += dk + c;
+    }
+};
+
+// block-level sum of up to four doubles per thread into partials[which * kPartials + blockIdx.x]
+template <int NV>
+__device__ __forceinline__ void block_sums(double (&acc)[NV], double *__restrict__ partials) {
+    __shared__ double part[NV][kBlock / 64];
+#pragma unroll
+    for (int s = 0; s < NV; s++) {
+        double a = acc[s];
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+        if ((threadIdx.x & 63) == 0) part[s][threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int s = 0; s < NV; s++) {
+            double a = part[s][0];
+            for (int wv = 1; wv < kBlock / 64; wv++) a += part[s][wv];
+            partials[s * kPartials + blockIdx.x] = a;
+        }
+    }
+}
+
+// sum of the `nb` block partials of slot `which`, by one block, fixed order
+__device__ __forceinline__ double sum_partials(const double *__restrict__ partials, int which, int nb) {
+    __shared__ double part[kBlock / 64];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kBlock) a += partials[which * kPartials + i];
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+    __syncthreads();  // `part` may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double s = part[0];
+    for (int wv = 1; wv < kBlock / 64; wv++) s += part[wv];
+    return s;
+}
+
+// divVelocity :124-141 (+ makeRHS :143-160 when WITH_RHS): per cell, grid-stride
+template <typename T, bool WITH_RHS>
+__global__ __launch_bounds__(kBlock) void grid_div_kernel(GridDev<T> G, const T *__restrict__ u,
+                                                          const T *__restrict__ v, const T *__restrict__ w,
+                                                          T *__restrict__ divU, T *__restrict__ b,
+                                                          double *__restrict__ partials) {
+    double acc[1] = {0.0};
+    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) {
+        const int i = cw.i, j = cw.j, k = cw.k;
+        const unsigned t = cw.t;
+        T div = 0;
+        div += u[u_id(G, i + 1, j, k)] - u[u_id(G, i, j, k)];
+        div += v[v_id(G, i, j + 1, k)] - v[v_id(G, i, j, k)];
+        div += w[w_id(G, i, j, k + 1)] - w[w_id(G, i, j, k)];
+        div /= G.h;
+        divU[t] = div;
+        acc[0] += (double)(div * div);
+        if (WITH_RHS) {
+            T rhs = -div;
+            if (j == 0) rhs += (0 - v[v_id(G, i, j, k)]) / G.h;
+            b[t] = rhs * G.rho * G.h * G.h / G.dt;
+        }
+    }
+    block_sums<1>(acc, partials);
+}
+
+__global__ __launch_bounds__(kBlock) void grid_divsum_kernel(const double *__restrict__ partials, int nb,
+                                                             double *__restrict__ out) {
+    const double s = sum_partials(partials, 0, nb);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// mvproduct :72-115 for one cell: the six terms in the order x-, x+, y-, y+, z-, z+; the floor (j = 0) is
+// a wall, the other five sides see p = 0 outside
+template <typename T>
+__device__ __forceinline__ T laplace_cell(const GridDev<T> &G, const T *__restrict__ x, const CellWalk<T> &cw) {
+    const int i = cw.i, j = cw.j, k = cw.k;
+    const size_t t = cw.t, sy = (size_t)G.nx, sz = (size_t)G.nx * (size_t)G.ny;
+    const T c = x[t];
+    T res = 0;
+    if (i == 0) res += c; else res += c - x[t - 1];
+    if (i == G.nx - 1) res += c; else res += c - x[t + 1];
+    if (j == 0) res += 0; else res += c - x[t - sy];
+    if (j == G.ny - 1) res += c; else res += c - x[t + sy];
+    if (k == 0) res += c; else res += c - x[t - sz];
+    if (k == G.nz - 1) res += c; else res += c - x[t + sz];
+    return res;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_mvproduct_kernel(GridDev<T> G, const T *__restrict__ x, T *__restrict__ dst) {
+    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) dst[cw.t] = laplace_cell(G, x, cw);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_dot_kernel(int n, const T *__restrict__ a, const T *__restrict__ b,
+                                                          double *__restrict__ partials) {
+    double acc[1] = {0.0};
+    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < (unsigned)n; t += gridDim.x * kBlock)
+        acc[0] += (double)(a[t] * b[t]);
+    block_sums<1>(acc, partials);
+}
+
+// ---- solve :162-214 -----------------------------------------------------------------------------------
+// :170-176: Aq = A p; r = b - Aq; q = r
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_init_kernel(GridDev<T> G, const T *__restrict__ p, const T *__restrict__ b,
+                                                         T *__restrict__ Aq, T *__restrict__ r, T *__restrict__ q) {
+    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) {
+        const unsigned t = cw.t;
+        const T a = laplace_cell(G, p, cw);
+        Aq[t] = a;
+        const T res = b[t] - a;
+        r[t] = res;
+        q[t] = res;
+    }
+}
+
+__global__ void cg_reset_kernel(CgState *cg, int maxiter) {
+    cg->rr = cg->qAq = cg->rr_new = cg->rabs_sum = 0.0;
+    cg->alpha = cg->beta = cg->rabs = 0.0;
+    cg->finished = cg->pending = 0;
+    cg->iter = 0;
+    cg->maxiter = maxiter;
+    cg->rounds = 0;
+}
+
+__device__ __forceinline__ bool cg_over(const CgState *cg) { return cg->finished != 0 || cg->pending != 0; }
+
+// :179-182: Aq = A q, and the partial sums of r.r and q.Aq
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_matvec_kernel(GridDev<T> G, const CgState *__restrict__ cg,
+                                                           const T *__restrict__ q, const T *__restrict__ r,
+                                                           T *__restrict__ Aq, double *__restrict__ partials) {
+    if (cg_over(cg)) return;
+    double acc[2] = {0.0, 0.0};
+    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) {
+        const unsigned t = cw.t;
+        const T a = laplace_cell(G, q, cw);
+        Aq[t] = a;
+        const T rv = r[t];
+        acc[0] += (double)(rv * rv);
+        acc[1] += (double)(q[t] * a);
+    }
+    block_sums<2>(acc, partials);
+}
+
+// :183-188: the "trivial all-zero" break and alpha = rr / qAq, in the solver's precision
+template <typename T> __global__ __launch_bounds__(kBlock) void cg_alpha_kernel(CgState *cg, const double *__restrict__ partials, int nb) {
+    if (cg_over(cg)) return;
+    const double rr = sum_partials(partials, 0, nb);
+    const double qAq = sum_partials(partials, 1, nb);
+    if (threadIdx.x != 0) return;
+    const T rrT = (T)rr, qAqT = (T)qAq;
+    cg->rr = (double)rrT;
+    cg->qAq = (double)qAqT;
+    if (rrT == 0 || qAqT == 0) {
+        cg->finished = 1;
+        return;
+    }
+    cg->alpha = (double)(T)(rrT / qAqT);
+}
+
+// :190-193 and the sums behind :195 and :201: p += alpha q; r -= alpha Aq; partial r.r and |r|
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(GridDev<T> G, const CgState *__restrict__ cg,
+                                                           const T *__restrict__ q, const T *__restrict__ Aq,
+                                                           T *__restrict__ p, T *__restrict__ r,
+                                                           double *__restrict__ partials) {
+    if (cg_over(cg)) return;
+    const T alpha = (T)cg->alpha;
+    double acc[2] = {0.0, 0.0};
+    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < (unsigned)G.dimSize; t += gridDim.x * kBlock) {
+        p[t] += alpha * q[t];
+        const T rv = r[t] - alpha * Aq[t];
+        r[t] = rv;
+        acc[0] += (double)(rv * rv);
+        acc[1] += (double)g_abs(rv);
+    }
+    block_sums<2>(acc, partials + 2 * kPartials);
+}
+
+// :195, :203-207: beta, the mean residual, the stop test, iter++ (and this build's optional cap)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_beta_kernel(CgState *cg, const double *__restrict__ partials, int nb, int n) {
+    if (cg_over(cg)) return;
+    const double rr_new = sum_partials(partials + 2 * kPartials, 0, nb);
+    const double rabs_sum = sum_partials(partials + 2 * kPartials, 1, nb);
+    if (threadIdx.x != 0) return;
+    const T rrT = (T)cg->rr;
+    cg->rr_new = (double)(T)rr_new;
+    cg->beta = (double)(T)((T)rr_new / rrT);
+    const T rabs = (T)rabs_sum / (T)n;
+    cg->rabs_sum = rabs_sum;
+    cg->rabs = (double)rabs;
+    cg->rounds++;
+    if ((double)rabs < 0.000001) {
+        cg->pending = 1;  // the direction update of this round still runs (:199-200 precede the test)
+        return;
+    }
+    cg->iter++;
+    if (cg->maxiter >= 0 && cg->iter >= cg->maxiter) cg->pending = 1;
+}
+
+// :199-200: q = r + beta q.  Runs in the round that ends the loop as well.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(GridDev<T> G, const CgState *__restrict__ cg,
+                                                              const T *__restrict__ r, T *__restrict__ q) {
+    if (cg->finished != 0) return;
+    const T beta = (T)cg->beta;
+    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < (unsigned)G.dimSize; t += gridDim.x * kBlock)
+        q[t] = r[t] + beta * q[t];
+}
+
+// one writer turns "pending" into "finished" once the direction update of the last round is through
+__global__ void cg_settle_kernel(CgState *cg) {
+    if (cg->pending != 0) {
+        cg->pending = 0;
+        cg->finished = 1;
+    }
+}
+
+// updateU :216-266, one thread per face and component (every face is updated by exactly one cell of the
+// reference's loop).  The maximum-velocity estimate of :251-256 only feeds a commented-out statement.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void grid_update_u_kernel(GridDev<T> G, const T *__restrict__ p, T *__restrict__ u,
+                                                               T *__restrict__ v, T *__restrict__ w) {
+    const T c = G.dt / G.rho / G.h;
+    const long long nu = (long long)(G.nx + 1) * G.ny * G.nz, nv = (long long)G.nx * (G.ny + 1) * G.nz,
+                    nw = (long long)G.nx * G.ny * (G.nz + 1);
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t < nu) {
+        const int ex = G.nx + 1;
+        const int i = (int)(t % ex), j = (int)((t / ex) % G.ny), k = (int)(t / ((long long)ex * G.ny));
+        T *f = &u[u_id(G, i, j, k)];
+        if (i == 0) *f -= (p[cell_id(G, 0, j, k)] - 0) * c;
+        else if (i < G.nx) *f -= (p[cell_id(G, i, j, k)] - p[cell_id(G, i - 1, j, k)]) * c;
+        else *f -= (0 - p[cell_id(G, G.nx - 1, j, k)]) * c;
+        return;
+    }
+    t -= nu;
+    if (t < nv) {
+        const int ey = G.ny + 1;
+        const int i = (int)(t % G.nx), j = (int)((t / G.nx) % ey), k = (int)(t / ((long long)G.nx * ey));
+        T *f = &v[v_id(G, i, j, k)];
+        if (j == 0) *f = 0;  // near solid
+        else if (j < G.ny) *f -= (p[cell_id(G, i, j, k)] - p[cell_id(G, i, j - 1, k)]) * c;
+        else *f -= (0 - p[cell_id(G, i, G.ny - 1, k)]) * c;
+        return;
+    }
+    t -= nv;
+    if (t < nw) {
+        const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((long long)G.nx * G.ny));
+        T *f = &w[w_id(G, i, j, k)];
+        if (k == 0) *f -= (p[cell_id(G, i, j, 0)] - 0) * c;
+        else if (k < G.nz) *f -= (p[cell_id(G, i, j, k)] - p[cell_id(G, i, j, k - 1)]) * c;
+        else *f -= (0 - p[cell_id(G, i, j, G.nz - 1)]) * c;
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+static inline int gblocks(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+static inline int rblocks(long long n) { return (int)std::min<long long>(kPartials, (n + kBlock - 1) / kBlock); }
+
+template <typename T> static void fill_dev(const GridSolver *g, GridDev<T> &G, const int dim[3], int pad, double h,
+                                           double dt, double rho) {
+    G.nx = dim[0]; G.ny = dim[1]; G.nz = dim[2]; G.pad = pad;
+    G.xlen = dim[0] + 2 * pad; G.ylen = dim[1] + 2 * pad; G.zlen = dim[2] + 2 * pad;
+    G.ulen = G.xlen + 1; G.vlen = G.ylen + 1; G.wlen = G.zlen + 1;
+    G.dimSize = dim[0] * dim[1] * dim[2];
+    G.h = (T)h; G.dt = (T)dt; G.rho = (T)rho;
+    // loadConfig :26-28: `-grid.dim.x/2*grid.h` negates, divides as integers, then multiplies
+    G.xmin[0] = (T)(-dim[0] / 2) * G.h;
+    G.xmin[1] = 0;
+    G.xmin[2] = (T)(-dim[2] / 2) * G.h;
+    (void)g;
+}
+
+#define GRID_LAUNCH(kernel, grid, ...)                                                                      \
+    do {                                                                                                    \
+        if (g->precision == FSA_PRECISION_F32) {                                                            \
+            using T = float;                                                                                \
+            const GridDev<T> &G = g->gf;                                                                    \
+            (void)G;                                                                                        \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, g->stream, __VA_ARGS__);                \
+        } else {                                                                                            \
+            using T = double;                                                                               \
+            const GridDev<T> &G = g->gd;                                                                    \
+            (void)G;                                                                                        \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, g->stream, __VA_ARGS__);                \
+        }                                                                                                   \
+        FSA_HIP(hipGetLastError());                                                                         \
+    } while (0)
+
+static void grid_free(GridSolver *g) {
+    void *ptrs[] = {g->u, g->v, g->w, g->uadv, g->vadv, g->wadv, g->p, g->divU, g->b, g->Aq, g->r, g->q,
+                    g->partials, g->cg, g->divsum, g->ppos, g->pcolor};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+}
+
+static int galloc(void **out, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return fail(FSA_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    e = hipMemset(*out, 0, bytes);
+    if (e != hipSuccess) return fail(FSA_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    return FSA_OK;
+}
+
+static int grid_advect(GridSolver *g) {
+    const long long nx = g->gf.nx, ny = g->gf.ny, nz = g->gf.nz;
+    GRID_LAUNCH((grid_advect_kernel<T, 0>), gblocks((nx + 1) * ny * nz), G, (const T *)g->u, (const T *)g->v,
+                (const T *)g->w, (T *)g->uadv);
+    GRID_LAUNCH((grid_advect_kernel<T, 1>), gblocks(nx * (ny + 1) * nz), G, (const T *)g->u, (const T *)g->v,
+                (const T *)g->w, (T *)g->vadv);
+    GRID_LAUNCH((grid_advect_kernel<T, 2>), gblocks(nx * ny * (nz + 1)), G, (const T *)g->u, (const T *)g->v,
+                (const T *)g->w, (T *)g->wadv);
+    std::swap(g->u, g->uadv);  // swapBuffer :573-577
+    std::swap(g->v, g->vadv);
+    std::swap(g->w, g->wadv);
+    return FSA_OK;
+}
+
+static int grid_advect_particles(GridSolver *g) {
+    if (g->n_particles == 0) return FSA_OK;
+    GRID_LAUNCH(grid_advect_particles_kernel<T>, gblocks(g->n_particles), G, g->n_particles, (const T *)g->u,
+                (const T *)g->v, (const T *)g->w, (T *)g->ppos, (T *)g->pcolor);
+    return FSA_OK;
+}
+
+static int grid_body_force(GridSolver *g) {
+    GRID_LAUNCH(grid_body_force_kernel<T>, gblocks((long long)g->gf.nx * (g->gf.ny + 1) * g->gf.nz), G, (T *)g->v);
+    return FSA_OK;
+}
+
+static int grid_div(GridSolver *g, bool with_rhs) {
+    const int nb = rblocks(g->dimSize);
+    if (with_rhs)
+        GRID_LAUNCH((grid_div_kernel<T, true>), nb, G, (const T *)g->u, (const T *)g->v, (const T *)g->w, (T *)g->divU,
+                    (T *)g->b, g->partials);
+    else
+        GRID_LAUNCH((grid_div_kernel<T, false>), nb, G, (const T *)g->u, (const T *)g->v, (const T *)g->w,
+                    (T *)g->divU, (T *)g->b, g->partials);
+    hipLaunchKernelGGL(grid_divsum_kernel, dim3(1), dim3(kBlock), 0, g->stream, g->partials, nb, g->divsum);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+static int grid_update_u(GridSolver *g) {
+    const long long nx = g->gf.nx, ny = g->gf.ny, nz = g->gf.nz;
+    const long long faces = (nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + 1);
+    GRID_LAUNCH(grid_update_u_kernel<T>, gblocks(faces), G, (const T *)g->p, (T *)g->u, (T *)g->v, (T *)g->w);
+    return FSA_OK;
+}
+
+constexpr int kCgBatch = 16;  // rounds launched between two looks at the loop state
+
+static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, int *rounds) {
+    const int nb = rblocks(g->dimSize);
+    hipLaunchKernelGGL(cg_reset_kernel, dim3(1), dim3(1), 0, g->stream, g->cg, maxiter);
+    GRID_LAUNCH(cg_init_kernel<T>, nb, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r, (T *)g->q);
+    CgState st{};
+    for (;;) {
+        for (int k = 0; k < kCgBatch; k++) {
+            GRID_LAUNCH(cg_matvec_kernel<T>, nb, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq, g->partials);
+            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, nb);
+            GRID_LAUNCH(cg_update_kernel<T>, nb, G, g->cg, (const T *)g->q, (const T *)g->Aq, (T *)g->p, (T *)g->r,
+                        g->partials);
+            GRID_LAUNCH(cg_beta_kernel<T>, 1, g->cg, g->partials, nb, g->dimSize);
+            GRID_LAUNCH(cg_direction_kernel<T>, nb, G, g->cg, (const T *)g->r, (T *)g->q);
+            hipLaunchKernelGGL(cg_settle_kernel, dim3(1), dim3(1), 0, g->stream, g->cg);
+        }
+        FSA_HIP(hipMemcpyAsync(&st, g->cg, sizeof(st), hipMemcpyDeviceToHost, g->stream));
+        FSA_HIP(hipStreamSynchronize(g->stream));
+        if (st.finished) break;
+    }
+    // :210
+    GRID_LAUNCH(grid_mvproduct_kernel<T>, nb, G, (const T *)g->p, (T *)g->Aq);
+    if (iters) *iters = st.iter;
+    if (residual) *residual = st.rabs;
+    if (rounds) *rounds = st.rounds;
+    return FSA_OK;
+}
+
+static void *grid_field(GridSolver *g, const std::string &k, size_t *count) {
+    const size_t U = (size_t)g->uSize, V = (size_t)g->vSize, W = (size_t)g->wSize, C = (size_t)g->dimSize;
+    if (k == "u") { *count = U; return g->u; }
+    if (k == "v") { *count = V; return g->v; }
+    if (k == "w") { *count = W; return g->w; }
+    if (k == "uadv") { *count = U; return g->uadv; }
+    if (k == "vadv") { *count = V; return g->vadv; }
+    if (k == "wadv") { *count = W; return g->wadv; }
+    if (k == "p") { *count = C; return g->p; }
+    if (k == "divU") { *count = C; return g->divU; }
+    if (k == "b") { *count = C; return g->b; }
+    if (k == "Aq") { *count = C; return g->Aq; }
+    if (k == "r") { *count = C; return g->r; }
+    if (k == "q") { *count = C; return g->q; }
+    return nullptr;
+}
+
+}  // namespace fsa
+
+using namespace fsa;
+
+#define GNEED(g)                                                        \
+    do {                                                                \
+        if (!(g)) return fail(FSA_ERR_INVALID, "grid solver is NULL");  \
+        FSA_HIP(hipSetDevice((g)->device));                             \
+    } while (0)
+#define GTRY(expr)           \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+extern "C" {
+
+int fsa_grid_create(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                    fsa_grid **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!dim || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0) return fail(FSA_ERR_INVALID, "dim must be positive");
+    // the advection reads one face outside the effective grid on every side
+    if (padding < 1) return fail(FSA_ERR_INVALID, "padding %d: at least 1 is needed", padding);
+    if (!(h > 0) || !(dt > 0) || !(rho > 0)) return fail(FSA_ERR_INVALID, "h, dt and rho must be positive");
+    if (precision != FSA_PRECISION_F32 && precision != FSA_PRECISION_F64)
+        return fail(FSA_ERR_INVALID, "unknown precision %d", precision);
+    const double faces = ((double)dim[0] + 2 * padding + 1) * ((double)dim[1] + 2 * padding + 1) *
+                         ((double)dim[2] + 2 * padding + 1);
+    if (faces >= 2147483647.0) return fail(FSA_ERR_INVALID, "grid too large for 32-bit face indices");
+    int ndev = 0;
+    FSA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(FSA_ERR_INVALID, "device %d of %d", device, ndev);
+    GridSolver *g = new (std::nothrow) GridSolver();
+    if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
+    g->precision = precision;
+    g->device = device;
+    fill_dev(g, g->gf, dim, padding, h, dt, rho);
+    fill_dev(g, g->gd, dim, padding, h, dt, rho);
+    g->uSize = g->gf.ulen * g->gf.ylen * g->gf.zlen;
+    g->vSize = g->gf.xlen * g->gf.vlen * g->gf.zlen;
+    g->wSize = g->gf.xlen * g->gf.ylen * g->gf.wlen;
+    g->dimSize = g->gf.dimSize;
+    int rc = FSA_OK;
+    if (hipSetDevice(device) != hipSuccess) rc = fail(FSA_ERR_HIP, "hipSetDevice failed");
+    if (rc == FSA_OK && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(FSA_ERR_HIP, "hipStreamCreate failed");
+    const size_t R = g->real_size();
+    void **face[] = {&g->u, &g->v, &g->w, &g->uadv, &g->vadv, &g->wadv};
+    const size_t face_n[] = {(size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize,
+                             (size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize};
+    for (int k = 0; k < 6 && rc == FSA_OK; k++) rc = galloc(face[k], face_n[k] * R);
+    void **cell[] = {&g->p, &g->divU, &g->b, &g->Aq, &g->r, &g->q};
+    for (int k = 0; k < 6 && rc == FSA_OK; k++) rc = galloc(cell[k], (size_t)g->dimSize * R);
+    if (rc == FSA_OK) rc = galloc((void **)&g->partials, 4 * kPartials * sizeof(double));
+    if (rc == FSA_OK) rc = galloc((void **)&g->cg, sizeof(CgState));
+    if (rc == FSA_OK) rc = galloc((void **)&g->divsum, sizeof(double));
+    if (rc != FSA_OK) {
+        grid_free(g);
+        delete g;
+        return rc;
+    }
+    *out = reinterpret_cast<fsa_grid *>(g);
+    return FSA_OK;
+}
+
+int fsa_grid_destroy(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    if (!g) return FSA_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    grid_free(g);
+    delete g;
+    return FSA_OK;
+}
+
+int fsa_grid_sizes(fsa_grid *hg, int sizes[4], double xmin[3]) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    if (!g) return fail(FSA_ERR_INVALID, "grid solver is NULL");
+    if (sizes) {
+        sizes[0] = g->uSize;
+        sizes[1] = g->vSize;
+        sizes[2] = g->wSize;
+        sizes[3] = g->dimSize;
+    }
+    if (xmin)
+        for (int a = 0; a < 3; a++) xmin[a] = g->precision == FSA_PRECISION_F32 ? (double)g->gf.xmin[a] : g->gd.xmin[a];
+    return FSA_OK;
+}
+
+int fsa_grid_synchronize(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    FSA_HIP(hipStreamSynchronize(g->stream));
+    return FSA_OK;
+}
+
+int fsa_grid_get_field(fsa_grid *hg, const char *name, void *dst, size_t bytes) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (!name || (!dst && bytes)) return fail(FSA_ERR_INVALID, "NULL argument");
+    size_t count = 0;
+    void *p = grid_field(g, name, &count);
+    if (!p) return fail(FSA_ERR_UNKNOWN_NAME, "unknown grid field '%s'", name);
+    if (bytes != count * g->real_size())
+        return fail(FSA_ERR_INVALID, "field '%s' is %zu bytes, caller passed %zu", name, count * g->real_size(), bytes);
+    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    return FSA_OK;
+}
+
+int fsa_grid_set_field(fsa_grid *hg, const char *name, const void *src, size_t bytes) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (!name || (!src && bytes)) return fail(FSA_ERR_INVALID, "NULL argument");
+    size_t count = 0;
+    void *p = grid_field(g, name, &count);
+    if (!p) return fail(FSA_ERR_UNKNOWN_NAME, "unknown grid field '%s'", name);
+    if (bytes != count * g->real_size())
+        return fail(FSA_ERR_INVALID, "field '%s' is %zu bytes, caller passed %zu", name, count * g->real_size(), bytes);
+    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    return FSA_OK;
+}
+
+int fsa_grid_set_particles(fsa_grid *hg, int n, const void *pos3) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (n < 0 || (n > 0 && !pos3)) return fail(FSA_ERR_INVALID, "bad particle array");
+    FSA_HIP(hipStreamSynchronize(g->stream));
+    const size_t R = g->real_size();
+    if (n > g->particle_cap) {
+        if (g->ppos) (void)hipFree(g->ppos);
+        if (g->pcolor) (void)hipFree(g->pcolor);
+        g->ppos = g->pcolor = nullptr;
+        g->particle_cap = 0;
+        GTRY(galloc(&g->ppos, (size_t)n * 3 * R));
+        GTRY(galloc(&g->pcolor, (size_t)n * 4 * R));
+        g->particle_cap = n;
+    }
+    g->n_particles = n;
+    if (n == 0) return FSA_OK;
+    FSA_HIP(hipMemcpy(g->ppos, pos3, (size_t)n * 3 * R, hipMemcpyHostToDevice));
+    // addParticles :635: colour (1, 1, 1, 1)
+    if (g->precision == FSA_PRECISION_F32) {
+        std::vector<float> one((size_t)n * 4, 1.f);
+        FSA_HIP(hipMemcpy(g->pcolor, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        std::vector<double> one((size_t)n * 4, 1.0);
+        FSA_HIP(hipMemcpy(g->pcolor, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return FSA_OK;
+}
+
+int fsa_grid_get_particles(fsa_grid *hg, void *pos3, void *color4, int *n) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (n) *n = g->n_particles;
+    FSA_HIP(hipStreamSynchronize(g->stream));
+    const size_t R = g->real_size(), N = (size_t)g->n_particles;
+    if (N == 0) return FSA_OK;
+    if (pos3) FSA_HIP(hipMemcpy(pos3, g->ppos, N * 3 * R, hipMemcpyDeviceToHost));
+    if (color4) FSA_HIP(hipMemcpy(color4, g->pcolor, N * 4 * R, hipMemcpyDeviceToHost));
+    return FSA_OK;
+}
+
+int fsa_grid_advect(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    return grid_advect(g);
+}
+
+int fsa_grid_advect_particles(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    return grid_advect_particles(g);
+}
+
+int fsa_grid_body_force(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    return grid_body_force(g);
+}
+
+int fsa_grid_testcase(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    GRID_LAUNCH(grid_testcase_kernel<T>, gblocks(g->dimSize), G, (T *)g->u, (T *)g->v, (T *)g->w);
+    return FSA_OK;
+}
+
+int fsa_grid_div_velocity(fsa_grid *hg, double *div_u_sum) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    GTRY(grid_div(g, false));
+    if (div_u_sum) {
+        FSA_HIP(hipMemcpyAsync(div_u_sum, g->divsum, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        FSA_HIP(hipStreamSynchronize(g->stream));
+    }
+    return FSA_OK;
+}
+
+int fsa_grid_make_rhs(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    return grid_div(g, true);
+}
+
+int fsa_grid_solve(fsa_grid *hg, int maxiter, int *iterations, double *residual) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    return grid_solve(g, maxiter, iterations, residual, nullptr);
+}
+
+int fsa_grid_update_u(fsa_grid *hg) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    return grid_update_u(g);
+}
+
+int fsa_grid_mvproduct(fsa_grid *hg, const char *src, const char *dst) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (!src || !dst) return fail(FSA_ERR_INVALID, "NULL argument");
+    size_t ca = 0, cb = 0;
+    void *a = grid_field(g, src, &ca), *b = grid_field(g, dst, &cb);
+    if (!a || !b || ca != (size_t)g->dimSize || cb != (size_t)g->dimSize || a == b)
+        return fail(FSA_ERR_INVALID, "mvproduct needs two different cell-centred fields");
+    GRID_LAUNCH(grid_mvproduct_kernel<T>, rblocks(g->dimSize), G, (const T *)a, (T *)b);
+    return FSA_OK;
+}
+
+int fsa_grid_dotproduct(fsa_grid *hg, const char *a_name, const char *b_name, double *out) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (!a_name || !b_name || !out) return fail(FSA_ERR_INVALID, "NULL argument");
+    size_t ca = 0, cb = 0;
+    void *a = grid_field(g, a_name, &ca), *b = grid_field(g, b_name, &cb);
+    if (!a || !b || ca != (size_t)g->dimSize || cb != (size_t)g->dimSize)
+        return fail(FSA_ERR_INVALID, "dotproduct needs two cell-centred fields");
+    const int nb = rblocks(g->dimSize);
+    GRID_LAUNCH(grid_dot_kernel<T>, nb, g->dimSize, (const T *)a, (const T *)b, g->partials);
+    hipLaunchKernelGGL(grid_divsum_kernel, dim3(1), dim3(kBlock), 0, g->stream, g->partials, nb, g->divsum);
+    FSA_HIP(hipGetLastError());
+    double s = 0.0;
+    FSA_HIP(hipMemcpyAsync(&s, g->divsum, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    FSA_HIP(hipStreamSynchronize(g->stream));
+    *out = g->precision == FSA_PRECISION_F32 ? (double)(float)s : s;
+    return FSA_OK;
+}
+
+int fsa_grid_step(fsa_grid *hg, int nsteps, int maxiter) {
+    GridSolver *g = reinterpret_cast<GridSolver *>(hg);
+    GNEED(g);
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    for (int k = 0; k < nsteps; k++) {  // Step :608-619
+        GTRY(grid_advect(g));
+        GTRY(grid_advect_particles(g));
+        GTRY(grid_body_force(g));
+        GTRY(grid_div(g, true));
+        GTRY(grid_solve(g, maxiter, nullptr, nullptr, nullptr));
+        GTRY(grid_update_u(g));
+        GTRY(grid_div(g, false));
+        g->frame++;
+    }
+    return FSA_OK;
+}
+
+}  // extern "C"

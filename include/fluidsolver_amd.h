@@ -326,6 +326,57 @@ int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
  * this solver (in a slab run one may arrive from a neighbour later). */
 int fsa_set_scene_has_rigid(fsa_solver *s, int has_rigid);
 
+/* ---- Eulerian grid solver ---------------------------------------------------
+ *
+ * The reference's other fluid solver: GridSolver (solver/grid_solver.h:52-108, solver/grid_solver.cpp), a
+ * staggered-grid solver with semi-Lagrangian advection, gravity, pressure projection by conjugate
+ * gradients and passive tracer particles, which the reference runs in host loops.  It is independent of the
+ * particle solvers above and has its own handle.  One entry per method of the class; `precision` as for
+ * fsa_create (the reference's `scalar` is float).
+ *
+ * Field names for fsa_grid_get_field / fsa_grid_set_field: u v w uadv vadv wadv (face-centred, padded, laid
+ * out as Grid::uId / vId / wId index them, solver/grid_solver.h:39-49) and p divU b Aq r q (cell-centred,
+ * dim.x * dim.y * dim.z, x fastest, Grid::cellId :36-38).
+ */
+typedef struct fsa_grid fsa_grid;
+/* loadConfig + allocate (solver/grid_solver.cpp:14-66) with the values of config/Eulerian.xml passed in:
+ * the low corner is (-dim.x/2*h, 0, -dim.z/2*h) as loadConfig sets it.  padding must be >= 1. */
+int fsa_grid_create(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                    fsa_grid **out);
+int fsa_grid_destroy(fsa_grid *g);
+/* sizes = {uSize, vSize, wSize, dimSize} (Grid::setSize, solver/grid_solver.h:23-35); either may be NULL */
+int fsa_grid_sizes(fsa_grid *g, int sizes[4], double xmin[3]);
+int fsa_grid_synchronize(fsa_grid *g);
+int fsa_grid_get_field(fsa_grid *g, const char *name, void *dst, size_t bytes); /* synchronises */
+int fsa_grid_set_field(fsa_grid *g, const char *name, const void *src, size_t bytes);
+/* tracer particles (addParticles :625-637 builds the reference's block; here the caller passes positions,
+ * n x 3 reals; colours start as 1,1,1,1) */
+int fsa_grid_set_particles(fsa_grid *g, int n, const void *pos3);
+int fsa_grid_get_particles(fsa_grid *g, void *pos3, void *color4, int *n); /* synchronises */
+/* advect :456-565 (u, v, w <- their advected copies), advectParticles :639-651, bodyForce :579-588,
+ * testcase :590-606 */
+int fsa_grid_advect(fsa_grid *g);
+int fsa_grid_advect_particles(fsa_grid *g);
+int fsa_grid_body_force(fsa_grid *g);
+int fsa_grid_testcase(fsa_grid *g);
+/* divVelocity :124-141: fills divU; *div_u_sum (may be NULL; asking for it synchronises) = sum of div^2 */
+int fsa_grid_div_velocity(fsa_grid *g, double *div_u_sum);
+/* makeRHS :143-160 (runs divVelocity first, as the reference does) */
+int fsa_grid_make_rhs(fsa_grid *g);
+/* solve :162-214: conjugate gradients on p from its current value until the mean |r| drops below 1e-6.
+ * The reference's loop has no bound; maxiter >= 0 adds one (counted like its `iter`), maxiter < 0 keeps it
+ * unbounded.  *iterations = final `iter`, *residual = last mean |r|; either may be NULL.  The dot products
+ * are reduced in double on the device; the loop's scalars stay there, so the host only looks at the state
+ * every 16 rounds.  Synchronises. */
+int fsa_grid_solve(fsa_grid *g, int maxiter, int *iterations, double *residual);
+/* updateU :216-266 */
+int fsa_grid_update_u(fsa_grid *g);
+/* mvproduct :72-115 and dotproduct :117-122 on named cell-centred fields */
+int fsa_grid_mvproduct(fsa_grid *g, const char *src, const char *dst);
+int fsa_grid_dotproduct(fsa_grid *g, const char *a, const char *b, double *out); /* synchronises */
+/* nsteps x GridSolver::Step :608-619 */
+int fsa_grid_step(fsa_grid *g, int nsteps, int maxiter);
+
 #ifdef __cplusplus
 }
 #endif

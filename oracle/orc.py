@@ -240,3 +240,138 @@ class OracleState:
 
     def solve_iisph(self, p, nsteps=1, mean_in_double=False):
         self.orc._solve_iisph(C.byref(p), self._s, int(nsteps), int(mean_in_double))
+
+
+# ---------------------------------------------------------------------------------------------
+# Eulerian grid solver (oracle/grid_oracle.c)
+# ---------------------------------------------------------------------------------------------
+_GRID_FACE = ("u", "v", "w", "uadv", "vadv", "wadv")
+_GRID_CELL = ("p", "divU", "b", "Aq", "r", "q")
+
+
+def _grid_struct(real):
+    class Grid(C.Structure):
+        _fields_ = ([("dim", C.c_int * 3), ("padding", C.c_int)] +
+                    [(k, C.c_int) for k in ("xlen", "ylen", "zlen", "ulen", "vlen", "wlen", "Size", "dimSize",
+                                            "uSize", "vSize", "wSize")] +
+                    [("xmin", real * 3), ("h", real), ("dt", real), ("rho", real)] +
+                    [(k, C.c_void_p) for k in _GRID_FACE + _GRID_CELL] +
+                    [("divUsum", real), ("frame", C.c_int), ("n_particles", C.c_int), ("pos", C.c_void_p),
+                     ("color", C.c_void_p)])
+    return Grid
+
+
+class GridOracle:
+    """One grid of the grid-solver oracle: GridOracle('f32', dim, padding, h, dt, rho)."""
+
+    def __init__(self, precision, dim, padding=1, h=0.02, dt=0.001, rho=1.0):
+        assert precision in ("f32", "f64")
+        self.real = C.c_float if precision == "f32" else C.c_double
+        self.dtype = np.float32 if precision == "f32" else np.float64
+        prefix = "gorc_" if precision == "f32" else "gorc64_"
+        path = os.path.join(_HERE, "libgorc32.so" if precision == "f32" else "libgorc64.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = C.CDLL(path)
+        self.Grid = _grid_struct(self.real)
+        G, RP = C.POINTER(self.Grid), C.POINTER(self.real)
+
+        def fn(name, restype, argtypes):
+            f = getattr(self.lib, prefix + name)
+            f.restype, f.argtypes = restype, argtypes
+            return f
+        self._create = fn("create", G, [C.POINTER(C.c_int), C.c_int, self.real, self.real, self.real])
+        self._destroy = fn("destroy", None, [G])
+        self._set_particles = fn("set_particles", None, [G, C.c_int, RP])
+        self._mvproduct = fn("mvproduct", None, [G, RP, RP])
+        self._dotproduct = fn("dotproduct", self.real, [G, RP, RP])
+        self._solve = fn("solve", C.c_int, [G, C.c_int, RP])
+        self._step = fn("step", None, [G, C.c_int])
+        for name in ("div_velocity", "make_rhs", "update_u", "advect", "body_force", "testcase", "advect_particles"):
+            setattr(self, "_" + name, fn(name, None, [G]))
+        for name in ("sample_u", "sample_v", "sample_w"):
+            setattr(self, "_" + name, fn(name, self.real, [G, RP]))
+        self._g = self._create((C.c_int * 3)(*dim), int(padding), h, dt, rho)
+        if not self._g:
+            raise MemoryError("gorc_create failed")
+        self.dim = tuple(int(d) for d in dim)
+        self.padding = int(padding)
+
+    # -- views ------------------------------------------------------------------
+    def _view(self, ptr, count, shape):
+        buf = (self.real * count).from_address(ptr)
+        return np.frombuffer(buf, dtype=self.dtype).reshape(shape)
+
+    def __getitem__(self, k):
+        """numpy view (no copy) of a field; face fields as (z, y, x) padded arrays, cell fields as (z, y, x).
+        The views of u/v/w change identity after advect (the buffers swap): fetch them again."""
+        g = self._g.contents
+        if k in _GRID_FACE:
+            shape = {"u": (g.zlen, g.ylen, g.ulen), "v": (g.zlen, g.vlen, g.xlen), "w": (g.wlen, g.ylen, g.xlen)}[k[0]]
+            return self._view(getattr(g, k), int(np.prod(shape)), shape)
+        if k in _GRID_CELL:
+            return self._view(getattr(g, k), g.dimSize, (g.dim[2], g.dim[1], g.dim[0]))
+        if k == "pos":
+            return self._view(g.pos, g.n_particles * 3, (g.n_particles, 3)) if g.n_particles else np.zeros((0, 3), self.dtype)
+        if k == "color":
+            return self._view(g.color, g.n_particles * 4, (g.n_particles, 4)) if g.n_particles else np.zeros((0, 4), self.dtype)
+        raise KeyError(k)
+
+    @property
+    def xmin(self): return np.array(self._g.contents.xmin[:], self.dtype)
+    @property
+    def h(self): return self._g.contents.h
+    @property
+    def dt(self): return self._g.contents.dt
+    @property
+    def rho(self): return self._g.contents.rho
+    @property
+    def div_u_sum(self): return self._g.contents.divUsum
+
+    def _p(self, a):
+        a = np.ascontiguousarray(a, self.dtype)
+        return a, a.ctypes.data_as(C.POINTER(self.real))
+
+    def set_particles(self, pos):
+        a, ptr = self._p(pos)
+        self._set_particles(self._g, len(a), ptr)
+
+    def mvproduct(self, v):
+        a, pa = self._p(v)
+        out = np.empty_like(a)
+        self._mvproduct(self._g, pa, out.ctypes.data_as(C.POINTER(self.real)))
+        return out
+
+    def dotproduct(self, a, b):
+        a, pa = self._p(a)
+        b, pb = self._p(b)
+        return self._dotproduct(self._g, pa, pb)
+
+    def sample(self, which, point):
+        a, pa = self._p(point)
+        return getattr(self, "_sample_" + which)(self._g, pa)
+
+    def solve(self, maxiter=-1):
+        r = self.real()
+        it = self._solve(self._g, int(maxiter), C.byref(r))
+        return it, r.value
+
+    def div_velocity(self): self._div_velocity(self._g)
+    def make_rhs(self): self._make_rhs(self._g)
+    def update_u(self): self._update_u(self._g)
+    def advect(self): self._advect(self._g)
+    def body_force(self): self._body_force(self._g)
+    def testcase(self): self._testcase(self._g)
+    def advect_particles(self): self._advect_particles(self._g)
+    def step(self, maxiter=-1): self._step(self._g, int(maxiter))
+
+    def close(self):
+        if self._g:
+            self._destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

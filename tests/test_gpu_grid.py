@@ -1,0 +1,186 @@
+"""The HIP grid solver through the C ABI against the oracle from the same state.  Every pass whose
+arithmetic is per cell or per face (advection, sampling of tracers, gravity, divergence, right-hand side,
+Laplacian, velocity update) must agree to 1e-5 (fp32) / 1e-10 (fp64) of the field's scale -- in practice
+bit for bit; the conjugate-gradient solve sums in a different order than the reference's float
+accumulators, so its result is held to the linear system instead (residual) and to the oracle's pressure
+within 1e-3 (fp32) / 1e-9 (fp64) of its scale."""
+import numpy as np
+import pytest
+
+from fluidsolver_amd import capi
+from oracle.orc import GridOracle
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = [((16, 32, 16), 1, "f32"), ((16, 32, 16), 1, "f64"), ((5, 7, 3), 2, "f32"), ((33, 9, 20), 1, "f64")]
+
+
+@pytest.fixture(params=CASES, ids=lambda c: f"{c[0][0]}x{c[0][1]}x{c[0][2]}-pad{c[1]}-{c[2]}")
+def pair(request):
+    dim, pad, prec = request.param
+    o = GridOracle(prec, dim, padding=pad, h=0.02, dt=0.001, rho=1.3)
+    g = capi.GridSolver(dim, padding=pad, h=0.02, dt=0.001, rho=1.3,
+                        precision=capi.PRECISION_F32 if prec == "f32" else capi.PRECISION_F64)
+    tol = 1e-5 if prec == "f32" else 1e-10
+    yield o, g, tol, prec
+    g.close()
+    o.close()
+
+
+def randomise(o, g, seed, scale=0.5):
+    rng = np.random.default_rng(seed)
+    for k in ("u", "v", "w"):
+        f = (scale * rng.standard_normal(o[k].shape)).astype(o.dtype)
+        o[k][...] = f
+        g.set(k, f)
+
+
+def same(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.tobytes() == b.tobytes() or rel_err(a, b) <= tol
+
+
+def test_sizes(pair):
+    o, g, tol, prec = pair
+    assert g.sizes == (o["u"].size, o["v"].size, o["w"].size, o["p"].size)
+    assert np.allclose(g.xmin, o.xmin, rtol=0, atol=0)
+
+
+def test_advection_and_tracers(pair):
+    o, g, tol, prec = pair
+    randomise(o, g, 11)
+    rng = np.random.default_rng(12)
+    nx, ny, nz = o.dim
+    lo = np.array([o.xmin[0], 0.0, o.xmin[2]])
+    pts = (lo + rng.random((500, 3)) * np.array([nx, ny, nz]) * o.h).astype(o.dtype)
+    pts[:20] += 3 * o.h  # a few outside the grid: velocity 0 there
+    o.set_particles(pts)
+    g.set_particles(pts)
+    o.advect_particles()
+    g.advect_particles()
+    pos, col = g.get_particles()
+    assert same(pos, o["pos"], tol) and same(col, o["color"], tol)
+    o.advect()
+    g.advect()
+    for k in ("u", "v", "w"):
+        assert same(g.get(k), o[k], tol), k
+    # large time step: back-traced points leave the grid and cross several cells
+    randomise(o, g, 13, scale=40.0)
+    o.advect()
+    g.advect()
+    for k in ("u", "v", "w"):
+        assert same(g.get(k), o[k], tol), k
+
+
+def test_gravity_divergence_rhs_and_update(pair):
+    o, g, tol, prec = pair
+    randomise(o, g, 21)
+    o.body_force()
+    g.body_force()
+    assert same(g.get("v"), o["v"], tol)
+    o.make_rhs()
+    g.make_rhs()
+    assert same(g.get("divU"), o["divU"], tol) and same(g.get("b"), o["b"], tol)
+    s = g.div_velocity()
+    o.div_velocity()
+    assert abs(s - o.div_u_sum) <= 1e-4 * o.div_u_sum  # the oracle adds it up in one float, in index order
+    p = np.random.default_rng(22).standard_normal(o["p"].shape).astype(o.dtype)
+    o["p"][...] = p
+    g.set("p", p)
+    o.update_u()
+    g.update_u()
+    for k in ("u", "v", "w"):
+        assert same(g.get(k), o[k], tol), k
+
+
+def test_laplacian_and_dot_product(pair):
+    o, g, tol, prec = pair
+    rng = np.random.default_rng(31)
+    q = rng.standard_normal(o["q"].shape).astype(o.dtype)
+    r = rng.standard_normal(o["q"].shape).astype(o.dtype)
+    g.set("q", q)
+    g.set("r", r)
+    g.mvproduct("q", "Aq")
+    assert same(g.get("Aq"), o.mvproduct(q), tol)
+    d_o = o.dotproduct(q, r)
+    d_g = g.dotproduct("q", "r")
+    exact = float((q.astype(np.float64) * r.astype(np.float64)).sum())
+    scale = float(np.abs(q.astype(np.float64) * r).sum())
+    assert abs(d_g - exact) <= (1e-6 if prec == "f32" else 1e-14) * scale
+    assert abs(d_g - d_o) <= (1e-5 if prec == "f32" else 1e-12) * scale
+
+
+def test_pressure_solve(pair):
+    o, g, tol, prec = pair
+    randomise(o, g, 41, scale=0.1)
+    o.make_rhs()
+    g.make_rhs()
+    it_o, res_o = o.solve(2000)
+    it_g, res_g = g.solve(2000)
+    assert res_g < 1e-6 and res_o < 1e-6
+    assert abs(it_g - it_o) <= max(2, it_o // 20)
+    p_g, p_o = g.get("p"), o["p"]
+    assert rel_err(p_g, p_o) <= (1e-3 if prec == "f32" else 1e-9)
+    # the solution satisfies the system as well as the oracle's does
+    b = o["b"].astype(np.float64)
+    r_g = np.abs(o.mvproduct(p_g).astype(np.float64) - b).mean()
+    r_o = np.abs(o.mvproduct(p_o.copy()).astype(np.float64) - b).mean()
+    assert r_g <= max(2 * r_o, 2e-6)
+    # Aq holds A p afterwards (:210)
+    assert same(g.get("Aq"), o.mvproduct(p_g), tol)
+
+
+def test_solve_with_an_iteration_cap_stops_where_the_oracle_stops(pair):
+    o, g, tol, prec = pair
+    randomise(o, g, 51, scale=0.1)
+    o.make_rhs()
+    g.make_rhs()
+    it_o, _ = o.solve(3)
+    it_g, _ = g.solve(3)
+    assert it_o == it_g == 3
+    assert rel_err(g.get("p"), o["p"]) <= 100 * tol
+    assert rel_err(g.get("q"), o["q"]) <= 1000 * tol  # the direction of the round that ended the loop is kept
+
+
+def test_all_zero_right_hand_side_ends_at_once(pair):
+    o, g, tol, prec = pair
+    o.make_rhs()
+    g.make_rhs()
+    assert o.solve(50)[0] == 0
+    it, res = g.solve(50)
+    assert it == 0
+    assert np.all(g.get("p") == 0)
+
+
+def test_five_steps(pair):
+    o, g, tol, prec = pair
+    rng = np.random.default_rng(61)
+    pts = (np.array([o.xmin[0], 0.0, o.xmin[2]]) + rng.random((200, 3)) * np.array(o.dim) * o.h).astype(o.dtype)
+    o.set_particles(pts)
+    g.set_particles(pts)
+    for _ in range(5):
+        o.step(2000)
+    g.step(5, 2000)
+    # each step's projection is solved to a mean residual of 1e-6 only, and a round more or less in one
+    # step (the two sides sum in a different order) moves the result by about that much
+    loose = 2e-3 if prec == "f32" else 1e-5
+    for k in ("u", "v", "w", "p"):
+        assert rel_err(g.get(k), o[k]) <= loose, k
+    pos, _ = g.get_particles()
+    assert np.abs(pos - o["pos"]).max() <= loose * o.h
+    assert g.div_velocity() < 1e-5
+
+
+def test_bad_arguments_are_rejected():
+    with pytest.raises(capi.FsaError):
+        capi.GridSolver((16, 16, 16), padding=0)
+    with pytest.raises(capi.FsaError):
+        capi.GridSolver((0, 16, 16))
+    g = capi.GridSolver((4, 4, 4))
+    with pytest.raises(capi.FsaError):
+        g.mvproduct("u", "p")
+    with pytest.raises(capi.FsaError):
+        check = g.lib.fsa_grid_get_field(g._h, b"nope", None, 0)
+        capi.check(check)
+    g.close()
