@@ -41,7 +41,7 @@ struct CgState {
     int pending;                       // 1: loop ends after this round's direction update
     int iter;                          // the reference's `iter`
     int maxiter;                       // < 0: none
-    int rounds;                        // rounds completed (diagnostic)
+    int rounds;                        // rounds completed
 };
 
 struct GridSolver {
@@ -234,30 +234,59 @@ __global__ __launch_bounds__(kBlock) void grid_testcase_kernel(GridDev<T> G, T *
     if (k == G.nz - 1) w[w_id(G, i, j, k + 1)] = (T)((k + 1) * 4);
 }
 
-// Grid-stride walk over the cells that keeps (i, j, k) by carrying instead of dividing per element.
-template <typename T> struct CellWalk {
-    unsigned t, stride;
-    int i, j, k, di, dj, dk;
-    __device__ __forceinline__ explicit CellWalk(const GridDev<T> &G) {
-        t = blockIdx.x * kBlock + threadIdx.x;
-        stride = gridDim.x * kBlock;
-        const unsigned plane = (unsigned)G.nx * (unsigned)G.ny;
-        i = (int)(t % (unsigned)G.nx);
-        j = (int)((t / (unsigned)G.nx) % (unsigned)G.ny);
+// Work split of the per-cell kernels.  The hardware deals consecutive block ids to the 8 XCDs in turn, each
+// with an L2 of its own.  The cells are cut into 8 contiguous slabs, one per XCD, and the blocks of an XCD sweep
+// their slab front to back, side by side: at any moment the chip streams through 8 compact windows (kind to
+// DRAM), and the +-x, +-y, +-z neighbours a stencil reads were fetched by the same XCD a moment ago or will be
+// used by it a moment later (grids launched here have a multiple of 8 blocks).
+constexpr unsigned kXcdCount = 8;
+struct CellSpan {
+    unsigned begin, end, stride;  // this thread's cells: begin, begin + stride, ... < end
+};
+__device__ __forceinline__ CellSpan cell_span(unsigned n) {
+    const unsigned per_xcd = gridDim.x / kXcdCount;
+    const unsigned xcd = blockIdx.x % kXcdCount, local = blockIdx.x / kXcdCount;
+    const unsigned sweep = per_xcd * kBlock;                                   // cells one XCD covers per pass
+    const unsigned slab = ((n + kXcdCount - 1) / kXcdCount + sweep - 1) / sweep * sweep;
+    const unsigned long long lo = (unsigned long long)xcd * slab, hi = lo + slab;
+    CellSpan sp;
+    sp.stride = sweep;
+    sp.end = hi < n ? (unsigned)hi : n;
+    const unsigned long long b = lo + (unsigned long long)local * kBlock + threadIdx.x;
+    sp.begin = b < sp.end ? (unsigned)b : sp.end;
+    return sp;
+}
+
+// Walk over a thread's cells that keeps (i, j, k) by carrying instead of dividing per element.  `nx`, `ny`
+// and `n` describe the array walked: the cells, or the groups of four cells along x.
+struct CellWalk {
+    unsigned t, end, stride;
+    int nx, ny, i, j, k, di, dj, dk;
+    __device__ __forceinline__ CellWalk(int nx_, int ny_, unsigned n) : nx(nx_), ny(ny_) {
+        const CellSpan sp = cell_span(n);
+        t = sp.begin;
+        end = sp.end;
+        stride = sp.stride;
+        const unsigned plane = (unsigned)nx * (unsigned)ny;
+        i = (int)(t % (unsigned)nx);
+        j = (int)((t / (unsigned)nx) % (unsigned)ny);
         k = (int)(t / plane);
-        di = (int)(stride % (unsigned)G.nx);
-        dj = (int)((stride / (unsigned)G.nx) % (unsigned)G.ny);
+        di = (int)(stride % (unsigned)nx);
+        dj = (int)((stride / (unsigned)nx) % (unsigned)ny);
         dk = (int)(stride / plane);
     }
-    __device__ __forceinline__ bool valid(const GridDev<T> &G) const { return t < (unsigned)G.dimSize; }
-    __device__ __forceinline__ void next(const GridDev<T> &G) {
-        t += stride;
+    template <typename T>
+    __device__ __forceinline__ explicit CellWalk(const GridDev<T> &G) : CellWalk(G.nx, G.ny, (unsigned)G.dimSize) {}
+    __device__ __forceinline__ bool valid() const { return t < end; }
+    __device__ __forceinline__ void next() {
+        // `end - t` cannot wrap: t < end here
+        t = end - t > stride ? t + stride : end;
         i += di;
-        int c = i >= G.nx ? 1 : 0;
-        i -= c ? G.nx : 0;
+        int c = i >= nx ? 1 : 0;
+        i -= c ? nx : 0;
         j += dj + c;
-        c = j >= G.ny ? 1 : 0;
-        j -= c ? G.ny : 0;
+        c = j >= ny ? 1 : 0;
+        j -= c ? ny : 0;
         k += dk + c;
     }
 };
@@ -284,7 +313,7 @@ __device__ __forceinline__ void block_sums(double (&acc)[NV], double *__restrict
 }
 
 // sum of the `nb` block partials of slot `which`, by one block, fixed order
-__device__ __forceinline__ double sum_partials(const double *__restrict__ partials, int which, int nb) {
+__device__ __forceinline__ double sum_partials(const double *partials, int which, int nb) {
     __shared__ double part[kBlock / 64];
     double a = 0.0;
     for (int i = threadIdx.x; i < nb; i += kBlock) a += partials[which * kPartials + i];
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void grid_div_kernel(GridDev<T> G, const T 
                                                           T *__restrict__ divU, T *__restrict__ b,
                                                           double *__restrict__ partials) {
     double acc[1] = {0.0};
-    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) {
+    for (CellWalk cw(G); cw.valid(); cw.next()) {
         const int i = cw.i, j = cw.j, k = cw.k;
         const unsigned t = cw.t;
         T div = 0;
@@ -332,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void grid_divsum_kernel(const double *__res
 // mvproduct :72-115 for one cell: the six terms in the order x-, x+, y-, y+, z-, z+; the floor (j = 0) is
 // a wall, the other five sides see p = 0 outside
 template <typename T>
-__device__ __forceinline__ T laplace_cell(const GridDev<T> &G, const T *__restrict__ x, const CellWalk<T> &cw) {
+__device__ __forceinline__ T laplace_cell(const GridDev<T> &G, const T *__restrict__ x, const CellWalk &cw) {
     const int i = cw.i, j = cw.j, k = cw.k;
     const size_t t = cw.t, sy = (size_t)G.nx, sz = (size_t)G.nx * (size_t)G.ny;
     const T c = x[t];
@@ -346,26 +375,82 @@ __device__ __forceinline__ T laplace_cell(const GridDev<T> &G, const T *__restri
     return res;
 }
 
+// Four cells along x at once (rows are a multiple of four long, so a group never straddles two rows and its
+// loads are aligned): the same six terms per cell, in the same order.
+template <typename T> struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+
 template <typename T>
+__device__ __forceinline__ Quad<T> laplace_quad(const GridDev<T> &G, const T *__restrict__ x, const CellWalk &qw,
+                                                Quad<T> &centre) {
+    const int i0 = qw.i * 4, j = qw.j, k = qw.k;
+    const size_t t = (size_t)qw.t * 4, sy = (size_t)G.nx, sz = (size_t)G.nx * (size_t)G.ny;
+    const Quad<T> zero{{0, 0, 0, 0}};
+    const Quad<T> c = *reinterpret_cast<const Quad<T> *>(x + t);
+    const Quad<T> ym = j > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sy) : zero;
+    const Quad<T> yp = j < G.ny - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sy) : zero;
+    const Quad<T> zm = k > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sz) : zero;
+    const Quad<T> zp = k < G.nz - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sz) : zero;
+    const T xm = i0 > 0 ? x[t - 1] : (T)0, xp = i0 + 4 < G.nx ? x[t + 4] : (T)0;
+    Quad<T> out;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const T cc = c.v[e];
+        const T left = e == 0 ? xm : c.v[e > 0 ? e - 1 : 0], right = e == 3 ? xp : c.v[e < 3 ? e + 1 : 3];
+        T res = 0;
+        if (i0 + e == 0) res += cc; else res += cc - left;
+        if (i0 + e == G.nx - 1) res += cc; else res += cc - right;
+        if (j == 0) res += 0; else res += cc - ym.v[e];
+        if (j == G.ny - 1) res += cc; else res += cc - yp.v[e];
+        if (k == 0) res += cc; else res += cc - zm.v[e];
+        if (k == G.nz - 1) res += cc; else res += cc - zp.v[e];
+        out.v[e] = res;
+    }
+    centre = c;
+    return out;
+}
+
+template <typename T, bool QUAD>
 __global__ __launch_bounds__(kBlock) void grid_mvproduct_kernel(GridDev<T> G, const T *__restrict__ x, T *__restrict__ dst) {
-    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) dst[cw.t] = laplace_cell(G, x, cw);
+    if (QUAD) {
+        for (CellWalk qw(G.nx / 4, G.ny, (unsigned)G.dimSize / 4); qw.valid(); qw.next()) {
+            Quad<T> c;
+            reinterpret_cast<Quad<T> *>(dst)[qw.t] = laplace_quad(G, x, qw, c);
+        }
+        return;
+    }
+    for (CellWalk cw(G); cw.valid(); cw.next()) dst[cw.t] = laplace_cell(G, x, cw);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void grid_dot_kernel(int n, const T *__restrict__ a, const T *__restrict__ b,
                                                           double *__restrict__ partials) {
     double acc[1] = {0.0};
-    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < (unsigned)n; t += gridDim.x * kBlock)
+    const CellSpan sp = cell_span((unsigned)n);
+    for (unsigned t = sp.begin; t < sp.end; t = sp.end - t > sp.stride ? t + sp.stride : sp.end)
         acc[0] += (double)(a[t] * b[t]);
     block_sums<1>(acc, partials);
 }
 
 // ---- solve :162-214 -----------------------------------------------------------------------------------
 // :170-176: Aq = A p; r = b - Aq; q = r
-template <typename T>
+template <typename T, bool QUAD>
 __global__ __launch_bounds__(kBlock) void cg_init_kernel(GridDev<T> G, const T *__restrict__ p, const T *__restrict__ b,
                                                          T *__restrict__ Aq, T *__restrict__ r, T *__restrict__ q) {
-    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) {
+    if (QUAD) {
+        for (CellWalk qw(G.nx / 4, G.ny, (unsigned)G.dimSize / 4); qw.valid(); qw.next()) {
+            Quad<T> c;
+            const Quad<T> a = laplace_quad(G, p, qw, c);
+            const Quad<T> bb = reinterpret_cast<const Quad<T> *>(b)[qw.t];
+            Quad<T> res;
+#pragma unroll
+            for (int e = 0; e < 4; e++) res.v[e] = bb.v[e] - a.v[e];
+            reinterpret_cast<Quad<T> *>(Aq)[qw.t] = a;
+            reinterpret_cast<Quad<T> *>(r)[qw.t] = res;
+            reinterpret_cast<Quad<T> *>(q)[qw.t] = res;
+        }
+        return;
+    }
+    for (CellWalk cw(G); cw.valid(); cw.next()) {
         const unsigned t = cw.t;
         const T a = laplace_cell(G, p, cw);
         Aq[t] = a;
@@ -387,25 +472,40 @@ __global__ void cg_reset_kernel(CgState *cg, int maxiter) {
 __device__ __forceinline__ bool cg_over(const CgState *cg) { return cg->finished != 0 || cg->pending != 0; }
 
 // :179-182: Aq = A q, and the partial sums of r.r and q.Aq
-template <typename T>
+template <typename T, bool QUAD>
 __global__ __launch_bounds__(kBlock) void cg_matvec_kernel(GridDev<T> G, const CgState *__restrict__ cg,
                                                            const T *__restrict__ q, const T *__restrict__ r,
                                                            T *__restrict__ Aq, double *__restrict__ partials) {
     if (cg_over(cg)) return;
     double acc[2] = {0.0, 0.0};
-    for (CellWalk<T> cw(G); cw.valid(G); cw.next(G)) {
-        const unsigned t = cw.t;
-        const T a = laplace_cell(G, q, cw);
-        Aq[t] = a;
-        const T rv = r[t];
-        acc[0] += (double)(rv * rv);
-        acc[1] += (double)(q[t] * a);
+    if (QUAD) {
+        for (CellWalk qw(G.nx / 4, G.ny, (unsigned)G.dimSize / 4); qw.valid(); qw.next()) {
+            Quad<T> c;
+            const Quad<T> a = laplace_quad(G, q, qw, c);
+            const Quad<T> rv = reinterpret_cast<const Quad<T> *>(r)[qw.t];
+            reinterpret_cast<Quad<T> *>(Aq)[qw.t] = a;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[0] += (double)(rv.v[e] * rv.v[e]);
+                acc[1] += (double)(c.v[e] * a.v[e]);
+            }
+        }
+    } else {
+        for (CellWalk cw(G); cw.valid(); cw.next()) {
+            const unsigned t = cw.t;
+            const T a = laplace_cell(G, q, cw);
+            Aq[t] = a;
+            const T rv = r[t];
+            acc[0] += (double)(rv * rv);
+            acc[1] += (double)(q[t] * a);
+        }
     }
     block_sums<2>(acc, partials);
 }
 
 // :183-188: the "trivial all-zero" break and alpha = rr / qAq, in the solver's precision
-template <typename T> __global__ __launch_bounds__(kBlock) void cg_alpha_kernel(CgState *cg, const double *__restrict__ partials, int nb) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_alpha_kernel(CgState *cg, const double *__restrict__ partials, int nb) {
     if (cg_over(cg)) return;
     const double rr = sum_partials(partials, 0, nb);
     const double qAq = sum_partials(partials, 1, nb);
@@ -429,7 +529,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(GridDev<T> G, const C
     if (cg_over(cg)) return;
     const T alpha = (T)cg->alpha;
     double acc[2] = {0.0, 0.0};
-    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < (unsigned)G.dimSize; t += gridDim.x * kBlock) {
+    const CellSpan sp = cell_span((unsigned)G.dimSize);
+    for (unsigned t = sp.begin; t < sp.end; t = sp.end - t > sp.stride ? t + sp.stride : sp.end) {
         p[t] += alpha * q[t];
         const T rv = r[t] - alpha * Aq[t];
         r[t] = rv;
@@ -461,22 +562,16 @@ __global__ __launch_bounds__(kBlock) void cg_beta_kernel(CgState *cg, const doub
     if (cg->maxiter >= 0 && cg->iter >= cg->maxiter) cg->pending = 1;
 }
 
-// :199-200: q = r + beta q.  Runs in the round that ends the loop as well.
+// :199-200: q = r + beta q, for round number `round` (0-based, counted by the host as it launches): runs
+// only if that round's update ran, which also covers the round that ends the loop.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_direction_kernel(GridDev<T> G, const CgState *__restrict__ cg,
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(GridDev<T> G, const CgState *__restrict__ cg, int round,
                                                               const T *__restrict__ r, T *__restrict__ q) {
-    if (cg->finished != 0) return;
+    if (cg->finished != 0 || cg->rounds != round + 1) return;
     const T beta = (T)cg->beta;
-    for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < (unsigned)G.dimSize; t += gridDim.x * kBlock)
+    const CellSpan sp = cell_span((unsigned)G.dimSize);
+    for (unsigned t = sp.begin; t < sp.end; t = sp.end - t > sp.stride ? t + sp.stride : sp.end)
         q[t] = r[t] + beta * q[t];
-}
-
-// one writer turns "pending" into "finished" once the direction update of the last round is through
-__global__ void cg_settle_kernel(CgState *cg) {
-    if (cg->pending != 0) {
-        cg->pending = 0;
-        cg->finished = 1;
-    }
 }
 
 // updateU :216-266, one thread per face and component (every face is updated by exactly one cell of the
@@ -519,7 +614,11 @@ __global__ __launch_bounds__(kBlock) void grid_update_u_kernel(GridDev<T> G, con
 
 // ---- host side -----------------------------------------------------------------------------------------
 static inline int gblocks(long long n) { return (int)((n + kBlock - 1) / kBlock); }
-static inline int rblocks(long long n) { return (int)std::min<long long>(kPartials, (n + kBlock - 1) / kBlock); }
+// blocks of a per-cell kernel: a multiple of the XCD count, at most one partial-sum slot each
+static inline int rblocks(long long n) {
+    const long long want = std::min<long long>(kPartials, (n + kBlock - 1) / kBlock);
+    return (int)((want + kXcdCount - 1) / kXcdCount * kXcdCount);
+}
 
 template <typename T> static void fill_dev(const GridSolver *g, GridDev<T> &G, const int dim[3], int pad, double h,
                                            double dt, double rho) {
@@ -619,24 +718,39 @@ constexpr int kCgBatch = 16;  // rounds launched between two looks at the loop s
 static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, int *rounds) {
     const int nb = rblocks(g->dimSize);
     hipLaunchKernelGGL(cg_reset_kernel, dim3(1), dim3(1), 0, g->stream, g->cg, maxiter);
-    GRID_LAUNCH(cg_init_kernel<T>, nb, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r, (T *)g->q);
+    const bool quad = g->gf.nx % 4 == 0;
+    const int nbq = quad ? rblocks(g->dimSize / 4) : nb;  // blocks of the stencil kernels
+    if (quad)
+        GRID_LAUNCH((cg_init_kernel<T, true>), nbq, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
+                    (T *)g->q);
+    else
+        GRID_LAUNCH((cg_init_kernel<T, false>), nb, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
+                    (T *)g->q);
     CgState st{};
+    int round = 0;
     for (;;) {
-        for (int k = 0; k < kCgBatch; k++) {
-            GRID_LAUNCH(cg_matvec_kernel<T>, nb, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq, g->partials);
-            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, nb);
+        for (int k = 0; k < kCgBatch; k++, round++) {
+            if (quad)
+                GRID_LAUNCH((cg_matvec_kernel<T, true>), nbq, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
+                            g->partials);
+            else
+                GRID_LAUNCH((cg_matvec_kernel<T, false>), nb, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
+                            g->partials);
+            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, nbq);
             GRID_LAUNCH(cg_update_kernel<T>, nb, G, g->cg, (const T *)g->q, (const T *)g->Aq, (T *)g->p, (T *)g->r,
                         g->partials);
             GRID_LAUNCH(cg_beta_kernel<T>, 1, g->cg, g->partials, nb, g->dimSize);
-            GRID_LAUNCH(cg_direction_kernel<T>, nb, G, g->cg, (const T *)g->r, (T *)g->q);
-            hipLaunchKernelGGL(cg_settle_kernel, dim3(1), dim3(1), 0, g->stream, g->cg);
+            GRID_LAUNCH(cg_direction_kernel<T>, nb, G, g->cg, round, (const T *)g->r, (T *)g->q);
         }
         FSA_HIP(hipMemcpyAsync(&st, g->cg, sizeof(st), hipMemcpyDeviceToHost, g->stream));
         FSA_HIP(hipStreamSynchronize(g->stream));
-        if (st.finished) break;
+        if (st.finished || st.pending) break;
     }
     // :210
-    GRID_LAUNCH(grid_mvproduct_kernel<T>, nb, G, (const T *)g->p, (T *)g->Aq);
+    if (quad)
+        GRID_LAUNCH((grid_mvproduct_kernel<T, true>), nbq, G, (const T *)g->p, (T *)g->Aq);
+    else
+        GRID_LAUNCH((grid_mvproduct_kernel<T, false>), nb, G, (const T *)g->p, (T *)g->Aq);
     if (iters) *iters = st.iter;
     if (residual) *residual = st.rabs;
     if (rounds) *rounds = st.rounds;
@@ -888,7 +1002,10 @@ int fsa_grid_mvproduct(fsa_grid *hg, const char *src, const char *dst) {
     void *a = grid_field(g, src, &ca), *b = grid_field(g, dst, &cb);
     if (!a || !b || ca != (size_t)g->dimSize || cb != (size_t)g->dimSize || a == b)
         return fail(FSA_ERR_INVALID, "mvproduct needs two different cell-centred fields");
-    GRID_LAUNCH(grid_mvproduct_kernel<T>, rblocks(g->dimSize), G, (const T *)a, (T *)b);
+    if (g->gf.nx % 4 == 0)
+        GRID_LAUNCH((grid_mvproduct_kernel<T, true>), rblocks(g->dimSize / 4), G, (const T *)a, (T *)b);
+    else
+        GRID_LAUNCH((grid_mvproduct_kernel<T, false>), rblocks(g->dimSize), G, (const T *)a, (T *)b);
     return FSA_OK;
 }
 
