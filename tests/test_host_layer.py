@@ -239,3 +239,53 @@ def test_headless_program_iisph_mode_on_the_shipped_scene(tmp_path):
     fluid = s.get("type") == 0
     assert s.get("density")[fluid].max() < 1.05 * 750.0  # the block's rest density
     s.close()
+
+
+def grid_tracers():
+    """addParticles (solver/grid_solver.cpp:625-637 of the reference): float loop counters, double bounds"""
+    f = np.float32
+    out = []
+    i = f(0)
+    while float(i) < 0.2:
+        j = f(0)
+        while float(j) < 0.1:
+            k = f(0)
+            while float(k) < 0.2:
+                out.append((f(-0.1) + i, f(0.01) + j, f(-0.1) + k))
+                k = f(float(k) + 0.01)
+            j = f(float(j) + 0.01)
+        i = f(float(i) + 0.01)
+    return np.array(out, np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "bin", "grid_solver")), reason="host layer not built")
+def test_headless_grid_solver_matches_python_binding(tmp_path):
+    """GridSolver::setup + Step through the plugin class on the shipped Eulerian.xml values"""
+    from fluidsolver_amd import capi
+    frames = 4
+    final = tmp_path / "grid.bin"
+    e = dict(os.environ, FSA_CONFIG_DIR=os.path.join(HOST, "config"))
+    subprocess.check_call([os.path.join(HOST, "bin", "grid_solver"), "--frames", str(frames), "--save-final", str(final)],
+                          env=e, stdout=subprocess.DEVNULL, timeout=300)
+    raw = np.fromfile(final, dtype=np.uint8)
+    n = int(raw[:4].view(np.int32)[0])
+    off = 4
+    pos = raw[off:off + n * 12].view(np.float32).reshape(n, 3)
+    off += n * 12
+    fields = {}
+    for name in ("u", "v", "w", "p"):
+        m = int(raw[off:off + 4].view(np.int32)[0])
+        fields[name] = raw[off + 4:off + 4 + 4 * m].view(np.float32)
+        off += 4 + 4 * m
+    g = capi.GridSolver((16, 32, 16), padding=1, h=0.02, dt=0.001, rho=1.0)
+    tr = grid_tracers()
+    assert len(tr) == n
+    g.set_particles(tr)
+    g.step(frames)
+    want_pos, _ = g.get_particles()
+    assert pos.tobytes() == want_pos.tobytes()
+    for name in ("u", "v", "w", "p"):
+        assert fields[name].tobytes() == g.get(name).tobytes(), name
+    assert np.abs(fields["v"]).max() > 0
+    g.close()
