@@ -15,6 +15,7 @@
 // batches and looks at the state between batches.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -379,18 +380,11 @@ __device__ __forceinline__ T laplace_cell(const GridDev<T> &G, const T *__restri
 // loads are aligned): the same six terms per cell, in the same order.
 template <typename T> struct alignas(4 * sizeof(T)) Quad { T v[4]; };
 
+// the six-term sums of four cells (i0 .. i0 + 3, j, k) from their values and their neighbours'
 template <typename T>
-__device__ __forceinline__ Quad<T> laplace_quad(const GridDev<T> &G, const T *__restrict__ x, const CellWalk &qw,
-                                                Quad<T> &centre) {
-    const int i0 = qw.i * 4, j = qw.j, k = qw.k;
-    const size_t t = (size_t)qw.t * 4, sy = (size_t)G.nx, sz = (size_t)G.nx * (size_t)G.ny;
-    const Quad<T> zero{{0, 0, 0, 0}};
-    const Quad<T> c = *reinterpret_cast<const Quad<T> *>(x + t);
-    const Quad<T> ym = j > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sy) : zero;
-    const Quad<T> yp = j < G.ny - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sy) : zero;
-    const Quad<T> zm = k > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sz) : zero;
-    const Quad<T> zp = k < G.nz - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sz) : zero;
-    const T xm = i0 > 0 ? x[t - 1] : (T)0, xp = i0 + 4 < G.nx ? x[t + 4] : (T)0;
+__device__ __forceinline__ Quad<T> laplace_quad_terms(const GridDev<T> &G, int i0, int j, int k, const Quad<T> &c, T xm,
+                                                      T xp, const Quad<T> &ym, const Quad<T> &yp, const Quad<T> &zm,
+                                                      const Quad<T> &zp) {
     Quad<T> out;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -405,8 +399,23 @@ __device__ __forceinline__ Quad<T> laplace_quad(const GridDev<T> &G, const T *__
         if (k == G.nz - 1) res += cc; else res += cc - zp.v[e];
         out.v[e] = res;
     }
-    centre = c;
     return out;
+}
+
+template <typename T>
+__device__ __forceinline__ Quad<T> laplace_quad(const GridDev<T> &G, const T *__restrict__ x, const CellWalk &qw,
+                                                Quad<T> &centre) {
+    const int i0 = qw.i * 4, j = qw.j, k = qw.k;
+    const size_t t = (size_t)qw.t * 4, sy = (size_t)G.nx, sz = (size_t)G.nx * (size_t)G.ny;
+    const Quad<T> zero{{0, 0, 0, 0}};
+    const Quad<T> c = *reinterpret_cast<const Quad<T> *>(x + t);
+    const Quad<T> ym = j > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sy) : zero;
+    const Quad<T> yp = j < G.ny - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sy) : zero;
+    const Quad<T> zm = k > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sz) : zero;
+    const Quad<T> zp = k < G.nz - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sz) : zero;
+    const T xm = i0 > 0 ? x[t - 1] : (T)0, xp = i0 + 4 < G.nx ? x[t + 4] : (T)0;
+    centre = c;
+    return laplace_quad_terms(G, i0, j, k, c, xm, xp, ym, yp, zm, zp);
 }
 
 template <typename T, bool QUAD>
@@ -498,6 +507,67 @@ __global__ __launch_bounds__(kBlock) void cg_matvec_kernel(GridDev<T> G, const C
             const T rv = r[t];
             acc[0] += (double)(rv * rv);
             acc[1] += (double)(q[t] * a);
+        }
+    }
+    block_sums<2>(acc, partials);
+}
+
+// The same pass, marching along z.  A block owns a tile of whole rows (256 threads = 256 groups of four cells
+// = kBlock / (nx / 4) rows) and a run of z planes inside its XCD's slab; every thread keeps its column's
+// previous, current and next plane values in registers, so per plane it reads one new group of q (plus, for
+// the tile's first and last row, the neighbouring row) instead of five.  +-x and +-y neighbours inside the
+// tile come from LDS.  Needs nx / 4 to be a power of two <= 256; same six-term sums, same bits.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_matvec_march_kernel(GridDev<T> G, const CgState *__restrict__ cg,
+                                                                 const T *__restrict__ q, const T *__restrict__ r,
+                                                                 T *__restrict__ Aq, double *__restrict__ partials,
+                                                                 int tiles, int zsegs) {
+    if (cg_over(cg)) return;
+    __shared__ Quad<T> tile[2][kBlock];
+    const int qx = G.nx >> 2, rows = kBlock / qx;
+    const int xcd = blockIdx.x % kXcdCount, local = blockIdx.x / kXcdCount;
+    const int tile_id = local % tiles, zseg = local / tiles;
+    const int slab = (G.nz + (int)kXcdCount - 1) / (int)kXcdCount, seglen = (slab + zsegs - 1) / zsegs;
+    const int kbeg = xcd * slab + zseg * seglen;
+    const int kend = min(min(kbeg + seglen, (xcd + 1) * slab), G.nz);
+    const int row = threadIdx.x / qx, qc = threadIdx.x % qx;
+    const int j = tile_id * rows + row;
+    const bool active = j < G.ny;
+    const bool first_row = row == 0, last_row = row == rows - 1;
+    const Quad<T> *q4 = reinterpret_cast<const Quad<T> *>(q);
+    const Quad<T> *r4 = reinterpret_cast<const Quad<T> *>(r);
+    Quad<T> *Aq4 = reinterpret_cast<Quad<T> *>(Aq);
+    const Quad<T> zero{{0, 0, 0, 0}};
+    double acc[2] = {0.0, 0.0};
+    if (kbeg < kend) {  // the same for the whole block
+        const size_t rowq = (size_t)qx, planeq = rowq * (size_t)G.ny;
+        size_t Q = (size_t)kbeg * planeq + (size_t)(active ? j : 0) * rowq + (size_t)qc;
+        Quad<T> zm = (active && kbeg > 0) ? q4[Q - planeq] : zero;
+        Quad<T> c = active ? q4[Q] : zero;
+        for (int k = kbeg; k < kend; k++, Q += planeq) {
+            const int buf = (k - kbeg) & 1;
+            const Quad<T> zp = (active && k + 1 < G.nz) ? q4[Q + planeq] : zero;
+            const Quad<T> rv = active ? r4[Q] : zero;
+            Quad<T> ym = zero, yp = zero;
+            if (active && first_row && j > 0) ym = q4[Q - rowq];
+            if (active && last_row && j < G.ny - 1) yp = q4[Q + rowq];
+            tile[buf][threadIdx.x] = c;
+            __syncthreads();
+            if (active) {
+                if (!first_row) ym = tile[buf][threadIdx.x - qx];
+                if (!last_row && j < G.ny - 1) yp = tile[buf][threadIdx.x + qx];
+                const T xm = qc > 0 ? tile[buf][threadIdx.x - 1].v[3] : (T)0;
+                const T xp = qc < qx - 1 ? tile[buf][threadIdx.x + 1].v[0] : (T)0;
+                const Quad<T> a = laplace_quad_terms(G, qc * 4, j, k, c, xm, xp, ym, yp, zm, zp);
+                Aq4[Q] = a;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc[0] += (double)(rv.v[e] * rv.v[e]);
+                    acc[1] += (double)(c.v[e] * a.v[e]);
+                }
+            }
+            zm = c;
+            c = zp;
         }
     }
     block_sums<2>(acc, partials);
@@ -720,6 +790,18 @@ static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, 
     hipLaunchKernelGGL(cg_reset_kernel, dim3(1), dim3(1), 0, g->stream, g->cg, maxiter);
     const bool quad = g->gf.nx % 4 == 0;
     const int nbq = quad ? rblocks(g->dimSize / 4) : nb;  // blocks of the stencil kernels
+    // the z-marching stencil: rows of a power-of-two number of four-cell groups, and few enough tiles
+    const int qx = g->gf.nx / 4;
+    bool march = quad && qx <= kBlock && (qx & (qx - 1)) == 0 && !std::getenv("FSA_GRID_NO_MARCH");
+    int tiles = 0, zsegs = 0, nbm = 0;
+    if (march) {
+        const int rows = kBlock / qx, slab = (g->gf.nz + (int)kXcdCount - 1) / (int)kXcdCount;
+        tiles = (g->gf.ny + rows - 1) / rows;
+        zsegs = std::max(1, std::min(slab, (kPartials / (int)kXcdCount) / std::max(tiles, 1)));
+        nbm = (int)kXcdCount * tiles * zsegs;
+        if (tiles > kPartials / (int)kXcdCount) march = false;
+    }
+    const int nb_dots = march ? nbm : nbq;
     if (quad)
         GRID_LAUNCH((cg_init_kernel<T, true>), nbq, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
                     (T *)g->q);
@@ -730,13 +812,16 @@ static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, 
     int round = 0;
     for (;;) {
         for (int k = 0; k < kCgBatch; k++, round++) {
-            if (quad)
+            if (march)
+                GRID_LAUNCH(cg_matvec_march_kernel<T>, nbm, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
+                            g->partials, tiles, zsegs);
+            else if (quad)
                 GRID_LAUNCH((cg_matvec_kernel<T, true>), nbq, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
                             g->partials);
             else
                 GRID_LAUNCH((cg_matvec_kernel<T, false>), nb, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
                             g->partials);
-            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, nbq);
+            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, nb_dots);
             GRID_LAUNCH(cg_update_kernel<T>, nb, G, g->cg, (const T *)g->q, (const T *)g->Aq, (T *)g->p, (T *)g->r,
                         g->partials);
             GRID_LAUNCH(cg_beta_kernel<T>, 1, g->cg, g->partials, nb, g->dimSize);

@@ -13,7 +13,11 @@ from util import rel_err
 
 pytestmark = pytest.mark.gpu
 
-CASES = [((16, 32, 16), 1, "f32"), ((16, 32, 16), 1, "f64"), ((5, 7, 3), 2, "f32"), ((33, 9, 20), 1, "f64")]
+# (16, 32, 16) is the shipped configuration; rows of 4 / 16 four-cell groups take the z-marching stencil (with
+# a partly empty tile and z slabs of unequal length in the 64-wide case), 12-wide rows the plain four-cell
+# stencil, the odd widths the one-cell stencil
+CASES = [((16, 32, 16), 1, "f32"), ((16, 32, 16), 1, "f64"), ((5, 7, 3), 2, "f32"), ((33, 9, 20), 1, "f64"),
+         ((12, 5, 6), 1, "f32"), ((64, 10, 20), 1, "f64"), ((64, 37, 19), 1, "f32")]
 
 
 @pytest.fixture(params=CASES, ids=lambda c: f"{c[0][0]}x{c[0][1]}x{c[0][2]}-pad{c[1]}-{c[2]}")
