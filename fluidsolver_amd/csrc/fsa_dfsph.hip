@@ -27,9 +27,8 @@ template <typename T> struct AlphaPolicy {
     static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
         return Nb{reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
     }
-    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj, int, T xx, T xy,
-                                                T xz,
-                                                T d2, const Vec4<T> &, const Nb &nb) {
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         if (self) return;
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
@@ -75,9 +74,8 @@ template <typename T> struct NpfPolicy {
         S.F.fx = S.F.fy = S.F.fz = 0;
     }
     static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.velMass[j], A.density[j]}; }
-    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj, int, T xx, T xy,
-                                                T xz,
-                                                T d2, const Vec4<T> &pj, const Nb &nb) {
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &pj, const Nb &nb) {
         const T sr = P.sr, sr2 = sr * sr;
         if (!self && tj == FSA_TYPE_FLUID) {
             if (d2 >= sr2) return;
@@ -130,9 +128,8 @@ template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
         const Vec3<T> v = A.vStarIn[j];
         return Nb{v.x, v.y, v.z, reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
     }
-    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj, int, T xx, T xy,
-                                                T xz,
-                                                T d2, const Vec4<T> &, const Nb &nb) {
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         if (self) return;
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
@@ -184,9 +181,8 @@ template <typename T, bool PACKED> struct ApplyPolicy {
         if (PACKED) return Nb{A.aux2[2 * (size_t)j], A.aux2[2 * (size_t)j + 1]};
         return Nb{A.pstiffIn[j] / A.density[j], reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
     }
-    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj, int, T xx, T xy,
-                                                T xz,
-                                                T d2, const Vec4<T> &, const Nb &nb) {
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         if (self || tj != FSA_TYPE_FLUID) return;
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
@@ -226,8 +222,8 @@ template <typename T> struct DensityRigidPolicy {
         S.rd = A.restDensity[index];
     }
     static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.restDensity[j]}; }
-    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj, int, T xx, T xy, T xz,
-                                                T d2,
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj, int,
+                                                T xx, T xy, T xz, T d2,
                                                 const Vec4<T> &, const Nb &nb) {
         const T sr2 = P.sr * P.sr;
         if (d2 >= sr2) return;
