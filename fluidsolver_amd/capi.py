@@ -36,7 +36,7 @@ EXPORTS = (
     "fsa_correct_density_error", "fsa_correct_divergence_error", "fsa_setup_dfsph", "fsa_step_dfsph",
     "fsa_non_pressure_force_multiphase", "fsa_iisph_factor", "fsa_iisph_predict_density", "fsa_iisph_calc_dijpjl",
     "fsa_iisph_calc_new_pressure", "fsa_iisph_solve_pressure", "fsa_iisph_calc_pressure_force", "fsa_iisph_update",
-    "fsa_setup_iisph", "fsa_step_iisph",
+    "fsa_setup_iisph", "fsa_step_iisph", "fsa_set_volume_fractions", "fsa_effective_mass",
     "fsa_grid_create", "fsa_grid_destroy", "fsa_grid_sizes", "fsa_grid_synchronize", "fsa_grid_get_field",
     "fsa_grid_set_field", "fsa_grid_set_particles", "fsa_grid_get_particles", "fsa_grid_advect",
     "fsa_grid_advect_particles", "fsa_grid_body_force", "fsa_grid_testcase", "fsa_grid_div_velocity",
@@ -145,6 +145,7 @@ def load() -> C.CDLL:
         "fsa_iisph_calc_dijpjl": [H], "fsa_iisph_calc_new_pressure": [H], "fsa_iisph_calc_pressure_force": [H],
         "fsa_iisph_update": [H], "fsa_setup_iisph": [H], "fsa_step_iisph": [H, C.c_int],
         "fsa_iisph_solve_pressure": [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)],
+        "fsa_set_volume_fractions": [H, C.c_int, C.POINTER(C.c_double), C.c_void_p], "fsa_effective_mass": [H],
         "fsa_grid_create": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                             C.POINTER(C.c_void_p)],
         "fsa_grid_destroy": [H], "fsa_grid_sizes": [H, C.POINTER(C.c_int), C.POINTER(C.c_double)],
@@ -356,6 +357,14 @@ class Solver:
     def iisph_update(self): check(self.lib.fsa_iisph_update(self._h))
     def setup_iisph(self): check(self.lib.fsa_setup_iisph(self._h))
     def step_iisph(self, nsteps: int = 1): check(self.lib.fsa_step_iisph(self._h, int(nsteps)))
+
+    def effective_mass(self): check(self.lib.fsa_effective_mass(self._h))
+
+    def set_volume_fractions(self, dens_arr, vfrac):
+        """vfrac: (n, typenum) rows in the current device order"""
+        vf = np.ascontiguousarray(vfrac, self.dtype)
+        da = (C.c_double * vf.shape[1])(*[float(d) for d in dens_arr])
+        check(self.lib.fsa_set_volume_fractions(self._h, vf.shape[1], da, _ptr(vf)))
 
     def iisph_solve_pressure(self, maxiter=10):
         it, e = C.c_int(), C.c_double()

@@ -110,7 +110,7 @@ static void free_all(Solver *s) {
     void *ptrs[] = {b.posType[0], b.posType[1], b.velMass[0], b.velMass[1], b.restDensity[0], b.restDensity[1],
                     b.uniqueId[0], b.uniqueId[1], b.density, b.pressure, b.force, b.v_star, b.v_star_alt, b.DF_factor, b.pstiff,
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
-                    b.density_star, b.groupSorted, b.hash, b.slot,
+                    b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
@@ -389,6 +389,12 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     s->count_valid = false;
     s->owned_from_sort = false;
     s->iisph = false;  // the per-position copy of group[] is rebuilt by the next IISPH call
+    if (s->typenum) {  // volume fractions belonged to the particles uploaded before
+        (void)hipFree(s->b.vFrac);
+        (void)hipFree(s->b.densArr);
+        s->b.vFrac = s->b.densArr = nullptr;
+        s->typenum = 0;
+    }
     if (n == 0) return FSA_OK;
 
     Staging sp, sv, st, sm;
@@ -899,6 +905,51 @@ IISPH_ENTRY(fsa_iisph_calc_dijpjl, launch_iisph_dijpjl)
 IISPH_ENTRY(fsa_iisph_calc_new_pressure, launch_iisph_new_pressure)
 IISPH_ENTRY(fsa_iisph_calc_pressure_force, launch_iisph_pressure_force)
 #undef IISPH_ENTRY
+
+int fsa_set_volume_fractions(fsa_solver *hs, int typenum, const double *dens_arr, const void *vfrac) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (s->slab) return fail(FSA_ERR_INVALID, "fsa_set_volume_fractions is not available in a slab solver");
+    if (typenum < 1 || typenum > 10) return fail(FSA_ERR_INVALID, "typenum %d outside 1..10", typenum);
+    if (!dens_arr || (s->n > 0 && !vfrac)) return fail(FSA_ERR_INVALID, "NULL argument");
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    const size_t N = (size_t)s->n, R = s->real_size(), K = (size_t)typenum;
+    if (typenum != s->typenum) {  // the one allocation after fsa_create, sized for the solver's capacity
+        if (s->b.vFrac) (void)hipFree(s->b.vFrac);
+        if (s->b.densArr) (void)hipFree(s->b.densArr);
+        s->b.vFrac = s->b.densArr = nullptr;
+        s->typenum = 0;
+        TRY(dalloc(s->b.vFrac, (size_t)s->capacity * K * R, true));
+        TRY(dalloc(s->b.densArr, K * R, true));
+        s->typenum = typenum;
+    }
+    // rows arrive in the current device order; they are kept in uniqueId order
+    std::vector<int> uid(N);
+    if (N) FSA_HIP(hipMemcpy(uid.data(), s->b.uniqueId[s->cur], N * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<unsigned char> table(N * K * R), dens(K * R);
+    for (size_t i = 0; i < N; i++)
+        memcpy(&table[(size_t)uid[i] * K * R], (const unsigned char *)vfrac + i * K * R, K * R);
+    for (size_t k = 0; k < K; k++) {
+        if (R == sizeof(float)) {
+            const float v = (float)dens_arr[k];
+            memcpy(&dens[k * R], &v, R);
+        } else {
+            memcpy(&dens[k * R], &dens_arr[k], R);
+        }
+    }
+    if (N) FSA_HIP(hipMemcpy(s->b.vFrac, table.data(), table.size(), hipMemcpyHostToDevice));
+    FSA_HIP(hipMemcpy(s->b.densArr, dens.data(), dens.size(), hipMemcpyHostToDevice));
+    return FSA_OK;
+}
+
+int fsa_effective_mass(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (s->slab) return fail(FSA_ERR_INVALID, "fsa_effective_mass is not available in a slab solver");
+    if (s->typenum == 0) return fail(FSA_ERR_INVALID, "fsa_effective_mass needs fsa_set_volume_fractions first");
+    s->pd_valid = false;
+    return launch_effective_mass(s);
+}
 
 int fsa_iisph_solve_pressure(fsa_solver *hs, int maxiter, int *rounds, double *last_mean) {
     Solver *s = reinterpret_cast<Solver *>(hs);

@@ -375,6 +375,39 @@ template <typename T> struct IisphPressureForcePolicy {
     }
 };
 
+// EffectiveMassKernel :1722-1755: mass, rest density and colour of a non-rigid particle from its volume
+// fractions (kept in uniqueId order, like colour; the reference carries the table through the sort).  The
+// printf on a vanishing beta is left out; effective_mass[] of the reference equals mass[].
+template <typename T>
+__global__ __launch_bounds__(kBlock) void effective_mass_kernel(DevParams<T> P, int n, T spacing, int typenum,
+                                                                const T *__restrict__ densArr,
+                                                                const T *__restrict__ vFrac,
+                                                                const int *__restrict__ uniqueId,
+                                                                const Vec4<T> *__restrict__ posType,
+                                                                Vec4<T> *__restrict__ velMass,
+                                                                T *__restrict__ restDensity, T *__restrict__ colorById) {
+    const int index = blockIdx.x * kBlock + threadIdx.x;
+    if (index >= n) return;
+    if (unpack_int(posType[index].w) == FSA_TYPE_RIGID) return;
+    const int uid = uniqueId[index];
+    const T *vol_frac = vFrac + (size_t)uid * (size_t)typenum;
+    const T rd = restDensity[index];
+    T rest_density = 0;
+    for (int k = 0; k < typenum; k++) {
+        const T mass_frac = vol_frac[k] * densArr[k] / rd;
+        if ((double)mass_frac < FSA_EPSILON) continue;
+        rest_density += vol_frac[k] * densArr[k];
+    }
+    Vec4<T> v = velMass[index];
+    v.w = rest_density * spacing * spacing * spacing;
+    velMass[index] = v;
+    restDensity[index] = rest_density;
+    T *c = colorById + 4 * (size_t)uid;
+    for (int k = 0; k < 3; k++) c[k] = k < typenum ? vol_frac[k] : (T)0;
+    c[3] = 1;
+    (void)P;
+}
+
 // IISPHUpdateKernel :4067-4076
 template <typename T>
 __global__ __launch_bounds__(kBlock) void iisph_integrate_kernel(DevParams<T> P, int n, Vec4<T> *__restrict__ posType,
@@ -434,6 +467,16 @@ __global__ __launch_bounds__(kBlock) void block_sum_kernel(int n, const T *__res
         DF_GENERIC(PolicyName<T>, tag);                                          \
         return FSA_OK;                                                           \
     } while (0)
+
+int launch_effective_mass(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "effective_mass");
+    const int c = s->cur;
+    DF_DISPATCH(effective_mass_kernel, (T)s->hp.spacing, s->typenum, (const T *)s->b.densArr, (const T *)s->b.vFrac,
+                s->b.uniqueId[c], (const Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
+                (T *)s->b.restDensity[c], (T *)s->b.color);
+    return FSA_OK;
+}
 
 int launch_npf_multiphase(Solver *s) { IISPH_PASS(NpfMultiPolicy, "npf_multiphase"); }
 int launch_iisph_factor(Solver *s) { IISPH_PASS(IisphFactorPolicy, "iisph_factor"); }

@@ -42,6 +42,8 @@ struct Buffers {
     void *aii = nullptr;
     void *density_star = nullptr;
     int *groupSorted = nullptr;    // group[] gathered into sorted order after each sort
+    void *vFrac = nullptr;         // typenum volume fractions per particle, uniqueId order (set on demand)
+    void *densArr = nullptr;       // typenum phase densities
     void *pd = nullptr;      // {pressure / density^2, density} pairs for the tuned force pass
     // neighbour search
     int *hash = nullptr;         // cell of particle i (device order before the sort)
@@ -95,6 +97,7 @@ struct Solver {
     bool pd_valid = false;  // pd[] matches density / pressure / mass of the current arrays ...
     bool pd_fast = false;   // ... in the fast flavour's layout
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
+    int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
@@ -148,6 +151,7 @@ int launch_update_position(Solver *s);
 int launch_update_velocities(Solver *s);
 int launch_max_error(Solver *s, double start, double *out);  // synchronises
 int launch_iisph_carry(Solver *s, int uid_buffer);  // part of the reorder when s->iisph
+int launch_effective_mass(Solver *s);
 int launch_npf_multiphase(Solver *s);
 int launch_iisph_factor(Solver *s);
 int launch_iisph_predict_density(Solver *s);

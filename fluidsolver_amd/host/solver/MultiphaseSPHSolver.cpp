@@ -234,15 +234,26 @@ void MultiphaseSPHSolver::SetupDFSPH() {
     }
 }
 
-// SetupIISPH, solver/MultiphaseSPHSolver.cpp:850-860.  Two of its calls have nothing to do here:
-// EffectiveMass recomputes mass and rest density from the volume fractions, which AddMultiphaseFluidVolumes
-// has already set to the same values for a fluid that does not change its mix, and InitializeDeformable
-// acts on TYPE_DEFORMABLE particles only.
+// SetupIISPH, solver/MultiphaseSPHSolver.cpp:850-860: Sort, EffectiveMass, IISPHFactor, RigidParticleVolume.
+// InitializeDeformable acts on TYPE_DEFORMABLE particles only and has no counterpart.
 void MultiphaseSPHSolver::SetupIISPH() {
     SetupFluidScene();
     run_mode = IISPH;
     if (numParticles > 0) {
-        check(fsa_setup_iisph(device), "SetupIISPH");
+        SortParticles();
+        // vol_frac is in creation order = uniqueId order; the library wants rows in the device's order
+        std::vector<int> uid((size_t)numParticles);
+        check(fsa_get_buffer(device, "uniqueId", uid.data(), uid.size() * sizeof(int)), "get uniqueId");
+        vecf rows((size_t)numParticles * maxtypenum);
+        for (int i = 0; i < numParticles; i++)
+            for (int t = 0; t < maxtypenum; t++)
+                rows[(size_t)i * maxtypenum + t] = vol_frac[(size_t)uid[i] * maxtypenum + t];
+        double dens[10];
+        for (int t = 0; t < maxtypenum; t++) dens[t] = densArr[t];
+        check(fsa_set_volume_fractions(device, maxtypenum, dens, rows.data()), "fsa_set_volume_fractions");
+        check(fsa_effective_mass(device), "EffectiveMass");
+        check(fsa_iisph_factor(device), "IISPHFactor");
+        check(fsa_rigid_particle_volume(device), "RigidParticleVolume");
         CopyPosColorFromDevice();
     }
 }

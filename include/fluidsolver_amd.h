@@ -226,6 +226,15 @@ int fsa_step_dfsph(fsa_solver *s, int nsteps);
  * for a wall in the fluid's group (solver/sph_kernel_impl.cuh:1173, 1214-1232); the reference leaves it
  * uninitialised, here it is whatever fsa_upload / fsa_set_buffer left (zero after an upload).
  */
+/* Volume fractions for EffectiveMass: typenum (1..10) fractions per particle, rows in the current device
+ * order (n x typenum reals), and <DensityArray>.  Kept per particle identity until the next fsa_upload; this
+ * call allocates the table (the only device allocation after fsa_create).  Synchronises. */
+int fsa_set_volume_fractions(fsa_solver *s, int typenum, const double *dens_arr, const void *vfrac);
+/* EffectiveMass (solver/sph_solver.cu:288-298, kernel solver/sph_kernel_impl.cuh:1722-1755): mass =
+ * rest density x spacing^3, rest density = sum of fraction x phase density, colour = the first three
+ * fractions, for every particle that is not TYPE_RIGID.  With fixed fractions this only re-rounds what the
+ * scene setup computed; SetupIISPH runs it once. */
+int fsa_effective_mass(fsa_solver *s);
 /* NonPressureForce_Multiphase: XSPH viscosity, surface tension, wall viscosity + friction, gravity -> v_star */
 int fsa_non_pressure_force_multiphase(fsa_solver *s);
 /* IISPHFactor: cubic-spline density and d_ii */
@@ -247,8 +256,9 @@ int fsa_iisph_calc_pressure_force(fsa_solver *s);
 /* IISPHUpdate: CalcPressureForceKernel + IISPHUpdateKernel (vel = v_star + F dt / m, pos += vel dt) */
 int fsa_iisph_update(fsa_solver *s);
 /* SetupIISPH after the scene is uploaded (solver/MultiphaseSPHSolver.cpp:850-860): sort, IISPHFactor,
- * RigidParticleVolume (EffectiveMass belongs to the multiphase model and InitializeDeformable to the
- * solids: neither acts on the particle types covered) */
+ * RigidParticleVolume (EffectiveMass, which sits between the sort and IISPHFactor in the reference, is the
+ * caller's to run first when it has volume fractions: fsa_sort_particles, fsa_effective_mass, then this;
+ * InitializeDeformable acts on deformable solids only) */
 int fsa_setup_iisph(fsa_solver *s);
 /* nsteps x SolveIISPH without the host read-back of positions */
 int fsa_step_iisph(fsa_solver *s, int nsteps);

@@ -100,6 +100,7 @@ class Oracle:
         for name in ("non_pressure_force_multiphase", "iisph_factor", "iisph_predict_density", "iisph_calc_dijpjl",
                      "iisph_calc_new_pressure", "iisph_calc_pressure_force", "iisph_update"):
             self._fn(name, None, [P, S])
+        self._fn("effective_mass", None, [P, S, C.c_int, C.POINTER(self.real), C.POINTER(self.real)])
         self._fn("iisph_solve_pressure", C.c_int, [P, S, C.c_int, C.c_int, C.POINTER(self.real)])
         self._fn("solve_iisph", None, [P, S, C.c_int, C.c_int])
 
@@ -225,6 +226,13 @@ class OracleState:
     def solve_dfsph(self, p, nsteps=1): self.orc._solve_dfsph(C.byref(p), self._s, int(nsteps))
 
     # IISPH ------------------------------------------------------------
+    def effective_mass(self, p, dens_arr, vfrac):
+        """vfrac: (n, typenum) in uniqueId order"""
+        vf = np.ascontiguousarray(vfrac, self.orc.dtype)
+        da = np.ascontiguousarray(dens_arr, self.orc.dtype)
+        RP = C.POINTER(self.orc.real)
+        self.orc._effective_mass(C.byref(p), self._s, vf.shape[1], da.ctypes.data_as(RP), vf.ctypes.data_as(RP))
+
     def non_pressure_force_multiphase(self, p): self.orc._non_pressure_force_multiphase(C.byref(p), self._s)
     def iisph_factor(self, p): self.orc._iisph_factor(C.byref(p), self._s)
     def iisph_predict_density(self, p): self.orc._iisph_predict_density(C.byref(p), self._s)

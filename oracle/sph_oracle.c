@@ -895,6 +895,28 @@ static inline int is_fluid_like(int t) { /* the three `case` labels that share o
     return t == ORC_TYPE_FLUID || t == ORC_TYPE_DEFORMABLE || t == ORC_TYPE_CLOTH;
 }
 
+/* EffectiveMassKernel :1722-1755 (the printf on a vanishing beta is left out; effective_mass[] = mass[]) */
+void ORC_NAME(effective_mass)(const params_t *p, state_t *s, int typenum, const R *dens_arr, const R *vfrac) {
+    const int n = s->n;
+    for (int index = 0; index < n; index++) {
+        if (s->type[index] == ORC_TYPE_RIGID) continue;
+        const R *vol_frac = vfrac + (size_t)s->uniqueId[index] * (size_t)typenum;
+        R beta = 0, rest_density = 0;
+        for (int k = 0; k < typenum; k++) {
+            R mass_frac = vol_frac[k] * dens_arr[k] / s->restDensity[index];
+            if ((double)mass_frac < ORC_EPSILON) continue;
+            beta += vol_frac[k] * vol_frac[k] / mass_frac;
+            rest_density += vol_frac[k] * dens_arr[k];
+        }
+        (void)beta;
+        s->mass[index] = rest_density * p->spacing * p->spacing * p->spacing;
+        s->restDensity[index] = rest_density;
+        /* color.Set(vol_frac[0], vol_frac[1], vol_frac[2], 1): the table has at least three columns there */
+        for (int k = 0; k < 3; k++) s->color[4 * (size_t)index + k] = k < typenum ? vol_frac[k] : 0;
+        s->color[4 * (size_t)index + 3] = 1;
+    }
+}
+
 /* NonPressureForceCell_Multiphase :1126-1262 + NonPressureForceKernel_Multiphase :1264-1306.
  * pow(float, int) in `fac` and `sr6` is taken as the double overload (C++11 promotion). */
 void ORC_NAME(non_pressure_force_multiphase)(const params_t *p, state_t *s) {

@@ -143,6 +143,12 @@ void ORC_NAME(solve_dfsph)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int ns
  * launchers solver/sph_solver.cu:300-310, 1388-1457; step MultiphaseSPHSolver.cpp:173-188).
  * Deformable and cloth particles are outside this restatement: their kernels
  * (ComputeTensionWithP_Kernel, UpdateSolidStateF_Kernel) do nothing for the types covered. ---- */
+/* EffectiveMassKernel, solver/sph_kernel_impl.cuh:1722-1755: mass, rest density and colour of every
+ * non-rigid particle from its volume fractions.  `vfrac` holds typenum fractions per particle in uniqueId
+ * order (the reference carries the table through the sort; reading it by uniqueId gives the same values),
+ * `dens_arr` is <DensityArray>. */
+void ORC_NAME(effective_mass)(const ORC_NAME(params) *p, ORC_NAME(state) *s, int typenum, const orc_real *dens_arr,
+                              const orc_real *vfrac);
 void ORC_NAME(non_pressure_force_multiphase)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
 void ORC_NAME(iisph_factor)(const ORC_NAME(params) *p, ORC_NAME(state) *s);
 void ORC_NAME(iisph_predict_density)(const ORC_NAME(params) *p, ORC_NAME(state) *s);

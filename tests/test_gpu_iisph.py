@@ -187,3 +187,47 @@ def test_iisph_entries_reject_slab_solvers_and_unsorted_states():
     with pytest.raises(capi.FsaError):
         slab.setup_iisph()
     slab.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_effective_mass_from_volume_fractions(prec, orc32, orc64):
+    """mass, rest density and colour of the non-rigid particles from a two-phase mix; rigid ones untouched"""
+    sc = scene("shipped_groups")
+    n = len(sc["pos"])
+    rng = np.random.default_rng(17)
+    a = rng.random(n)
+    vf = np.stack([a, 1 - a, np.zeros(n)], 1)
+    vf[::7] = (0.0, 0.0, 1.0)  # a vanishing fraction is skipped (mass_frac < EPSILON)
+    dens = (500.0, 1000.0, 1500.0)
+    if prec == "f64":
+        sc = dict(sc)
+        for k in ("pos", "vel", "color", "normal", "mass", "restDensity"):
+            sc[k] = np.asarray(sc[k], np.float64)
+    orc = orc32 if prec == "f32" else orc64
+    p_o, st = oracle_pair(orc, sc)
+    p_g, s = gpu_solver(sc, precision=capi.PRECISION_F32 if prec == "f32" else capi.PRECISION_F64)
+    with pytest.raises(capi.FsaError):
+        s.effective_mass()  # no fractions yet
+    st.sort_particles(p_o)
+    s.sort_particles()
+    uid = s.get("uniqueId")
+    s.set_volume_fractions(dens, vf[uid])  # rows in the current device order
+    st.effective_mass(p_o, dens, vf)
+    s.effective_mass()
+    for k in ("mass", "restDensity", "color"):
+        assert s.get(k).tobytes() == st[k].tobytes(), k
+    rigid = st["type"] == 4
+    assert np.all(s.get("restDensity")[rigid] == 0)
+    # the table stays with the particles through a sort
+    mv = (st["pos"] + rng.normal(0, 0.004, st["pos"].shape)).astype(st["pos"].dtype)
+    st["pos"][...] = mv
+    s.set("pos", mv)
+    st.sort_particles(p_o)
+    s.sort_particles()
+    st["mass"][...] = 0
+    s.set("mass", np.zeros(n, st["mass"].dtype))
+    st.effective_mass(p_o, dens, vf)
+    s.effective_mass()
+    assert s.get("mass").tobytes() == st["mass"].tobytes()
+    s.close()
+    st.close()

@@ -231,7 +231,14 @@ def test_headless_program_iisph_mode_on_the_shipped_scene(tmp_path):
     p = capi.make_params(capi.PRECISION_F32, **sc["params"])
     s = capi.Solver(p, len(sc["pos"]))
     s.upload(sc)
-    s.setup_iisph()
+    # SetupIISPH: Sort, EffectiveMass (VolFrac 0.5,0.5,0 of DensityArray 500,1000,1500), IISPHFactor, RigidParticleVolume
+    s.sort_particles()
+    vf = np.tile(np.asarray((0.5, 0.5, 0.0), np.float32), (len(sc["pos"]), 1))
+    vf[sc["type"][s.get("uniqueId")] != 0] = 0  # LoadPO leaves the wall particles' fractions at zero
+    s.set_volume_fractions((500.0, 1000.0, 1500.0), vf)
+    s.effective_mass()
+    s.iisph_factor()
+    s.rigid_particle_volume()
     s.step_iisph(frames)
     want, _ = s.readback_pos_color()
     assert np.isfinite(want).all()
