@@ -106,7 +106,8 @@ template <typename T> struct NpfPolicy {
 
 // ---- DensityChangeCell :775-813 / PredictDensityCell :846-887 and the two kernels around them -------
 // TIMES_DT = false: solveDivergenceStiff :818-842; true: solveDensityStiff :890-919
-template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
+// FAST (fp32, variant 2): hardware reciprocal square root and fused multiply-adds, about 1e-7 relative per term
+template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct StiffPolicy {
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T acc; Vec3<T> vs; };
@@ -133,6 +134,17 @@ template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
         if (self) return;
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
+        if (FAST) {
+            if (tj != FSA_TYPE_FLUID) return;
+            const float rinv = __builtin_amdgcn_rsqf((float)d2);
+            const float c = (float)sr - (float)d2 * rinv;
+            const float w = (float)P.kspikydiff * c * c * rinv * (float)nb.mass;
+            const float dot = __builtin_fmaf((float)(S.vs.x - nb.vx), (float)xx,
+                                             __builtin_fmaf((float)(S.vs.y - nb.vy), (float)xy,
+                                                            (float)(S.vs.z - nb.vz) * (float)xz)) * w;
+            S.acc = (T)__builtin_fmaf(dot, TIMES_DT ? (float)P.dt : 1.0f, (float)S.acc);
+            return;
+        }
         const T d = r_sqrt(d2);
         const T c = sr - d;
         const T nablaw = P.kspikydiff * c * c / d;
@@ -166,7 +178,7 @@ template <typename T, bool TIMES_DT, bool PACKED> struct StiffPolicy {
 // ---- applyPressureCell :921-961 + applyPStiff :963-984 ---------------------------------------------
 // Neighbours are read through pos / pstiff / density only, v_star is written for the particle itself:
 // no ordering hazard between threads.
-template <typename T, bool PACKED> struct ApplyPolicy {
+template <typename T, bool PACKED, bool FAST = false> struct ApplyPolicy {
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T wi, fx, fy, fz; };
@@ -186,6 +198,15 @@ template <typename T, bool PACKED> struct ApplyPolicy {
         if (self || tj != FSA_TYPE_FLUID) return;
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
+        if (FAST) {
+            const float rinv = __builtin_amdgcn_rsqf((float)d2);
+            const float c = (float)sr - (float)d2 * rinv;
+            const float f = (float)P.kspikydiff * c * c * rinv * (float)nb.mass * (float)(S.wi + nb.w);
+            S.fx = (T)__builtin_fmaf((float)xx, f, (float)S.fx);
+            S.fy = (T)__builtin_fmaf((float)xy, f, (float)S.fy);
+            S.fz = (T)__builtin_fmaf((float)xz, f, (float)S.fz);
+            return;
+        }
         // KernelGradient_Spiky :24-30
         const T d = r_sqrt(xx * xx + xy * xy + xz * xz);
         const T c = sr - d;
@@ -328,6 +349,8 @@ __global__ __launch_bounds__(kBlock) void block_max_kernel(int n, const T *__res
     }
 }
 
+static bool use_fast(const Solver *s) { return use_tiles(s) && s->variant >= 2; }
+
 static int pack_vstar_mass(Solver *s) {
     ScopedTimer t(s, "pack_vstar_mass");
     hipLaunchKernelGGL(pack_vstar_mass_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
@@ -369,6 +392,7 @@ int launch_solve_density_stiff(Solver *s) {
     if (use_tiles(s)) {
         int rc = pack_vstar_mass(s);
         if (rc) return rc;
+        if (use_fast(s)) return launch_tuned<StiffPolicy<float, true, true, true>>(s, "density_stiff");
         return launch_tuned<StiffPolicy<float, true, true>>(s, "density_stiff");
     }
     // (these policy names carry commas, which a macro argument cannot: hence the alias macro)
@@ -383,6 +407,7 @@ int launch_solve_divergence_stiff(Solver *s) {
     if (use_tiles(s)) {
         int rc = pack_vstar_mass(s);
         if (rc) return rc;
+        if (use_fast(s)) return launch_tuned<StiffPolicy<float, false, true, true>>(s, "divergence_stiff");
         return launch_tuned<StiffPolicy<float, false, true>>(s, "divergence_stiff");
     }
 #define FSA_POLICY StiffPolicy<T, false, false>
@@ -402,6 +427,7 @@ int launch_apply_pstiff(Solver *s) {
                                (const float4 *)s->b.velMass[s->cur], (float2 *)s->b.pd);
             FSA_HIP(hipGetLastError());
         }
+        if (use_fast(s)) return launch_tuned<ApplyPolicy<float, true, true>>(s, "apply_pstiff");
         return launch_tuned<ApplyPolicy<float, true>>(s, "apply_pstiff");
     }
 #define FSA_POLICY ApplyPolicy<T, false>

@@ -578,7 +578,7 @@ struct IisphNewPressureFastPolicy {
     }
 };
 
-static bool use_fast(const Solver *s) { return use_tiles(s) && s->variant >= 2 && !std::getenv("FSA_IISPH_EXACT"); }
+static bool use_fast(const Solver *s) { return use_tiles(s) && s->variant >= 2; }
 
 #define IISPH_PASS(PolicyName, tag)                                              \
     do {                                                                         \
