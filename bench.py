@@ -167,6 +167,19 @@ def main():
                     roof["traffic"] = t[key]
             except Exception:
                 pass
+        # second view of the same kernel: VALU issue slots (the pass is instruction-bound, not HBM-bound)
+        vprof = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vprof) and avg_s > 0:
+            try:
+                v = json.load(open(vprof))
+                key = f"{args.scene}:{dom}"
+                if key in v:
+                    peak = v["simds"] * v["clock_ghz"] * 1e9 / v["cycles_per_wave_inst"]
+                    rate = v[key]["valu_wave_insts"] / avg_s
+                    roof["valu_issue"] = {"wave_insts_per_launch": v[key]["valu_wave_insts"], "achieved_per_s": rate,
+                                          "peak_per_s": peak, "frac": rate / peak}
+            except Exception:
+                pass
     out = {
         "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus,
         "steps": steps, "warmup": args.warmup, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
