@@ -32,5 +32,8 @@ print(json.dumps({"scene": a.dims, "particles": len(sc["pos"]), "fluid": sc["n_f
                   "ms_per_step": wall / a.steps * 1e3,
                   "particle_steps_per_s": sc["n_fluid"] * a.steps / wall,
                   "max_density": float(s.get("density")[fl].max()), "finite": bool(np.isfinite(s.get("pos")).all()),
+                  "out_of_grid": s.num_undef(), "max_speed": float(np.abs(s.get("vel")[fl]).max()),
+                  "fluid_y_range": [float(s.get("pos")[fl][:, 1].min()), float(s.get("pos")[fl][:, 1].max())],
+                  "fluid_x_max": float(s.get("pos")[fl][:, 0].max()),
                   "kernels_ms_per_step": {k: round(ms / a.steps, 4) for k, (c, ms) in kt.items()},
                   "launches_per_step": {k: c / a.steps for k, (c, ms) in kt.items()}}))
