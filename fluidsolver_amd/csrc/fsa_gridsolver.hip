@@ -624,6 +624,10 @@ __global__ __launch_bounds__(kBlock) void cg_beta_kernel(CgState *cg, const doub
     cg->rabs_sum = rabs_sum;
     cg->rabs = (double)rabs;
     cg->rounds++;
+    if (!(rabs == rabs)) {  // not a number: no test of the reference's loop would ever end it
+        cg->finished = 2;
+        return;
+    }
     if ((double)rabs < 0.000001) {
         cg->pending = 1;  // the direction update of this round still runs (:199-200 precede the test)
         return;
@@ -831,6 +835,8 @@ static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, 
         FSA_HIP(hipStreamSynchronize(g->stream));
         if (st.finished || st.pending) break;
     }
+    if (st.finished == 2)
+        return fail(FSA_ERR_INVALID, "conjugate gradients: the residual is not a number after %d rounds", st.rounds);
     // :210
     if (quad)
         GRID_LAUNCH((grid_mvproduct_kernel<T, true>), nbq, G, (const T *)g->p, (T *)g->Aq);

@@ -379,7 +379,8 @@ int fsa_grid_make_rhs(fsa_grid *g);
  * The reference's loop has no bound; maxiter >= 0 adds one (counted like its `iter`), maxiter < 0 keeps it
  * unbounded.  *iterations = final `iter`, *residual = last mean |r|; either may be NULL.  The dot products
  * are reduced in double on the device; the loop's scalars stay there, so the host only looks at the state
- * every 16 rounds.  Synchronises. */
+ * every 16 rounds.  A residual that is not a number ends the loop with FSA_ERR_INVALID (the reference would
+ * spin forever).  Synchronises. */
 int fsa_grid_solve(fsa_grid *g, int maxiter, int *iterations, double *residual);
 /* updateU :216-266 */
 int fsa_grid_update_u(fsa_grid *g);

@@ -176,6 +176,19 @@ def test_five_steps(pair):
     assert g.div_velocity() < 1e-5
 
 
+def test_a_poisoned_right_hand_side_ends_the_solve_with_an_error():
+    g = capi.GridSolver((8, 8, 8))
+    b = np.zeros(g.shape("b"), np.float32)
+    b[3, 3, 3] = np.nan
+    u = np.zeros(g.shape("u"), np.float32)
+    u[4, 4, 4] = np.nan  # the divergence, hence b, is not a number
+    g.set("u", u)
+    g.make_rhs()
+    with pytest.raises(capi.FsaError):
+        g.solve(-1)
+    g.close()
+
+
 def test_bad_arguments_are_rejected():
     with pytest.raises(capi.FsaError):
         capi.GridSolver((16, 16, 16), padding=0)
