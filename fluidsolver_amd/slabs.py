@@ -499,7 +499,9 @@ def bench_distributed(args, build_scene):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # a rank that died must not leave the others waiting for the default half hour
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     props = torch.cuda.get_device_properties(device_index)
     ident = "|".join(str(getattr(props, a, "")) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
     if not ident.strip("|"):
