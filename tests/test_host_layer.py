@@ -296,3 +296,31 @@ def test_headless_grid_solver_matches_python_binding(tmp_path):
         assert fields[name].tobytes() == g.get(name).tobytes(), name
     assert np.abs(fields["v"]).max() > 0
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_run_mode_tag_of_the_scene_selects_the_step(tmp_path):
+    """<RunMode> IISPH </RunMode> inside the scene does what FSA_RUN_MODE=IISPH does; an unknown word fails loudly"""
+    import shutil
+    cfg = tmp_path / "config"
+    shutil.copytree(os.path.join(HOST, "config"), cfg)
+    text = (cfg / "sph_scene.xml").read_text()
+    marker = '<MultiScene id="2">'
+    assert marker in text
+    exe = os.path.join(HOST, "bin", "particle_solver")
+
+    def run(config_dir, extra_env, out):
+        e = dict(os.environ, FSA_CONFIG_DIR=str(config_dir), FSA_SCENE_ID="2", **extra_env)
+        e.pop("FSA_RUN_MODE", None) if "FSA_RUN_MODE" not in extra_env else None
+        return subprocess.run([exe, "--frames", "3", "--save-final", str(out)], env=e, stdout=subprocess.DEVNULL,
+                              stderr=subprocess.PIPE, timeout=300)
+
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    assert run(os.path.join(HOST, "config"), {"FSA_RUN_MODE": "IISPH"}, a).returncode == 0
+    (cfg / "sph_scene.xml").write_text(text.replace(marker, marker + "\n\t<RunMode> IISPH </RunMode>", 1))
+    assert run(cfg, {}, b).returncode == 0
+    assert read_final(a)[0].tobytes() == read_final(b)[0].tobytes()
+    (cfg / "sph_scene.xml").write_text(text.replace(marker, marker + "\n\t<RunMode> PBF </RunMode>", 1))
+    bad = run(cfg, {}, tmp_path / "c.bin")
+    assert bad.returncode != 0 and b"RunMode" in bad.stderr
