@@ -687,32 +687,13 @@ int launch_iisph_carry(Solver *s, int uid_buffer) {
 
 constexpr int kSumBlocks = 1024;
 
-// Mean of error[] over all particles (IISPHSolvePressure, solver/sph_solver.cu:1428-1436).  Variant 0
-// copies the array to the host and adds it up in a float, in index order, exactly as the reference does;
-// the other variants reduce on the device in double and round the mean once.
+// Mean of error[] over all particles (IISPHSolvePressure, solver/sph_solver.cu:1428-1436, where the array is
+// copied to the host and added up in one float in index order): reduced on the device in double over a fixed
+// tree, the mean rounded once to the solver's precision.
 int launch_mean_error(Solver *s, double *out) {
     *out = 0.0;
     if (s->n == 0) return FSA_OK;
     const int n = s->n;
-    if (s->variant == 0) {
-        FSA_HIP(hipStreamSynchronize(s->stream));
-        if (s->precision == FSA_PRECISION_F32) {
-            std::vector<float> e((size_t)n);
-            FSA_HIP(hipMemcpy(e.data(), s->b.error, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-            float sum = 0.f;
-            for (int i = 0; i < n; i++) sum += e[i];
-            sum /= n;
-            *out = sum;
-        } else {
-            std::vector<double> e((size_t)n);
-            FSA_HIP(hipMemcpy(e.data(), s->b.error, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-            double sum = 0.0;
-            for (int i = 0; i < n; i++) sum += e[i];
-            sum /= n;
-            *out = sum;
-        }
-        return FSA_OK;
-    }
     {
         ScopedTimer t(s, "mean_error");
         const int nb = std::min(kSumBlocks, blocks_for(n));

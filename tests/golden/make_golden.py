@@ -94,7 +94,7 @@ def generate_iisph(precision):
     st.iisph_predict_density(p)
     out["aii"] = st["aii"].copy()
     out["density_star"] = st["density_star"].copy()
-    rounds, mean = st.iisph_solve_pressure(p, 10)
+    rounds, mean = st.iisph_solve_pressure(p, 10, mean_in_double=True)
     out["rounds"] = np.int32(rounds)
     out["pressure"] = st["pressure"].copy()
     out["error"] = st["error"].copy()
@@ -104,7 +104,7 @@ def generate_iisph(precision):
     out["vel_after"] = st["vel"].copy()
     st.sort_particles(p)
     st.iisph_factor(p)
-    st.solve_iisph(p, 2)
+    st.solve_iisph(p, 2, mean_in_double=True)
     out["pos_step3_by_id"] = st["pos"][np.argsort(st["uniqueId"])].copy()
     st.close()
     path = os.path.join(HERE, f"iisph_tank_{precision}.npz")

@@ -201,7 +201,7 @@ def test_oracle_reproduces_the_iisph_golden(precision, orc32, orc64):
     st.iisph_predict_density(p)
     assert st["aii"].tobytes() == g["aii"].tobytes()
     assert st["density_star"].tobytes() == g["density_star"].tobytes()
-    rounds, _ = st.iisph_solve_pressure(p, 10)
+    rounds, _ = st.iisph_solve_pressure(p, 10, mean_in_double=True)
     assert rounds == int(g["rounds"])
     assert st["pressure"].tobytes() == g["pressure"].tobytes()
     st.iisph_update(p)
@@ -209,6 +209,6 @@ def test_oracle_reproduces_the_iisph_golden(precision, orc32, orc64):
     assert st["pos"].tobytes() == g["pos_after"].tobytes()
     st.sort_particles(p)
     st.iisph_factor(p)
-    st.solve_iisph(p, 2)
+    st.solve_iisph(p, 2, mean_in_double=True)
     assert st["pos"][np.argsort(st["uniqueId"])].tobytes() == g["pos_step3_by_id"].tobytes()
     st.close()
