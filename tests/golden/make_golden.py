@@ -7,7 +7,8 @@ The reference ships no golden vectors for this path and cannot be built here, so
 ORACLE (and, through the GPU tests, the HIP path) against silent change; they are not outputs of the
 reference.  One file per precision: the inputs of a small noisy dam break with wall particles and the
 outputs of every stage of one step, plus the positions after five whole steps; and, in iisph_tank_*.npz,
-the same for the IISPH step on a small tank whose wall uses the viscosity / friction branch.
+the same for the IISPH step on a small tank whose wall uses the viscosity / friction branch; and, in
+grid_16x32x16_*.npz, the stages of one step of the Eulerian grid solver on its shipped grid.
 """
 import json
 import os
@@ -112,7 +113,52 @@ def generate_iisph(precision):
     print(path, os.path.getsize(path), "bytes")
 
 
+def grid_inputs(precision):
+    """a noisy velocity field on the shipped 16 x 32 x 16 grid and 64 tracers"""
+    from oracle.orc import GridOracle
+    g = GridOracle(precision, (16, 32, 16), padding=1, h=0.02, dt=0.001, rho=1.0)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    fields = {k: (0.3 * rng.standard_normal(g[k].shape)).astype(g.dtype) for k in ("u", "v", "w")}
+    lo = np.array([g.xmin[0], 0.0, g.xmin[2]])
+    pts = (lo + rng.random((64, 3)) * np.array([16, 32, 16]) * 0.02).astype(g.dtype)
+    return g, fields, pts
+
+
+def generate_grid(precision):
+    g, fields, pts = grid_inputs(precision)
+    out = {"in_" + k: v for k, v in fields.items()}
+    out["in_tracers"] = pts
+    for k, v in fields.items():
+        g[k][...] = v
+    g.set_particles(pts)
+    g.advect()
+    for k in ("u", "v", "w"):
+        out["advected_" + k] = g[k].copy()
+    g.advect_particles()
+    out["tracers_after"] = g["pos"].copy()
+    g.body_force()
+    g.make_rhs()
+    out["divU"] = g["divU"].copy()
+    out["b"] = g["b"].copy()
+    it, res = g.solve(2000)
+    out["cg_iterations"] = np.int32(it)
+    out["p"] = g["p"].copy()
+    g.update_u()
+    for k in ("u", "v", "w"):
+        out["projected_" + k] = g[k].copy()
+    g.div_velocity()
+    g.step(2000)
+    g.step(2000)
+    out["p_step3"] = g["p"].copy()
+    g.close()
+    path = os.path.join(HERE, f"grid_16x32x16_{precision}.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
+    generate_grid("f32")
+    generate_grid("f64")
     generate("f32")
     generate("f64")
     generate_iisph("f32")

@@ -149,3 +149,35 @@ def test_the_shipped_configuration_runs_ten_steps_and_stays_divergence_free():
     pd = 1
     assert np.all(g["v"][pd:-pd, pd, pd:-pd] == 0)  # nothing crosses the floor
     g.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_oracle_reproduces_the_grid_golden(precision):
+    import os
+    from golden.make_golden import grid_inputs
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"grid_16x32x16_{precision}.npz")
+    gold = dict(np.load(path))
+    g, fields, pts = grid_inputs(precision)
+    for k, v in fields.items():
+        assert v.tobytes() == gold["in_" + k].tobytes()
+        g[k][...] = v
+    g.set_particles(pts)
+    g.advect()
+    for k in ("u", "v", "w"):
+        assert g[k].tobytes() == gold["advected_" + k].tobytes(), k
+    g.advect_particles()
+    assert g["pos"].tobytes() == gold["tracers_after"].tobytes()
+    g.body_force()
+    g.make_rhs()
+    assert g["divU"].tobytes() == gold["divU"].tobytes() and g["b"].tobytes() == gold["b"].tobytes()
+    it, _ = g.solve(2000)
+    assert it == int(gold["cg_iterations"])
+    assert g["p"].tobytes() == gold["p"].tobytes()
+    g.update_u()
+    for k in ("u", "v", "w"):
+        assert g[k].tobytes() == gold["projected_" + k].tobytes(), k
+    g.div_velocity()
+    g.step(2000)
+    g.step(2000)
+    assert g["p"].tobytes() == gold["p_step3"].tobytes()
+    g.close()
