@@ -482,6 +482,20 @@ def derive_grid(P):
 # bench entry (bench.py --gpus N under torch.distributed.run)
 # ------------------------------------------------------------------------------------------------
 def bench_distributed(args, build_scene):
+    """One rank of `bench.py --gpus N`.  The communication libraries print connection chatter to file
+    descriptor 1; it is pointed at stderr for the duration, so that stdout carries the bench line only."""
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _bench_distributed(args, build_scene)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+
+
+def _bench_distributed(args, build_scene):
     import torch
     import torch.distributed as dist
 
