@@ -83,6 +83,7 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.num_cells = h.gridres[0] * h.gridres[1] * d.nz;
     d.own_lo = -(1 << 30);
     d.own_hi = 1 << 30;
+    d.rows = nullptr;
 }
 
 static int check_params(const fsa_params *p) {
@@ -112,7 +113,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -285,6 +286,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.cellStart, (C + 8) * sizeof(int), true);
     ALLOC(b.gridCellStart, C * sizeof(int), true);
     ALLOC(b.gridCellEnd, C * sizeof(int), true);
+    ALLOC(b.blockRows, (nblocks + 8) * 20 * sizeof(int), true);
     ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
     ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);
     ALLOC(b.undefBlockStart, (nblocks + 8) * sizeof(int), true);
@@ -312,6 +314,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
         delete s;
         return rc;
     }
+    s->pf.rows = s->b.blockRows;
     *out = reinterpret_cast<fsa_solver *>(s);
     return FSA_OK;
 }
@@ -341,6 +344,7 @@ int fsa_copy_param_to_device(fsa_solver *hs, const fsa_params *p) {
     to_dev_params(*p, s->pd);
     s->pf.own_lo = s->pd.own_lo = own_lo;
     s->pf.own_hi = s->pd.own_hi = own_hi;
+    s->pf.rows = s->b.blockRows;
     invalidate_order(s);
     return FSA_OK;
 }

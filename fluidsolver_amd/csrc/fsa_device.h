@@ -59,6 +59,8 @@ template <typename T> struct DevParams {
     // z-slab runs: global layers [own_lo, own_hi) whose particles need forces (density: one layer more on
     // each side); what else the solver holds is halo, whose results nobody reads.  Default: everything.
     int own_lo, own_hi;
+    // fp32 solvers: the row table of the tiled passes for the current sorted order (see fsa_tile.h), else null
+    const int *rows;
 };
 
 __device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }

@@ -17,6 +17,7 @@
 #include <utility>
 
 #include "fsa_solver.h"
+#include "fsa_tile.h"
 
 namespace fsa {
 
@@ -276,6 +277,38 @@ __global__ __launch_bounds__(kBlock) void index_table_kernel(int n, const int *_
     indexTable[uniqueId[p]] = p;
 }
 
+// row table of the tiled neighbour passes (fsa_tile.h), one entry per block of kTunedBS sorted particles
+// 16 lanes per block entry: lanes 0..8 look up one row each, the verdict is folded over the 16 lanes
+__global__ __launch_bounds__(256) void block_rows_kernel(DevParams<float> P, int n, const int *__restrict__ cellStart,
+                                                         const int *__restrict__ sortedHash,
+                                                         int *__restrict__ table) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int blk = gid >> 4, r = gid & 15;
+    const int nblk = (n + kTunedBS - 1) / kTunedBS;
+    const bool live = blk < nblk;
+    int bad = 0;
+    if (live) {
+        const int b0 = blk * kTunedBS, nb = min(kTunedBS, n - b0);
+        const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+        const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
+        bad = grid_ok ? 0 : 1;
+        if (r < 9) {
+            int s, len;
+            block_row(P, hlo, hhi, grid_ok, r, cellStart, s, len);
+            int *row = table + (size_t)blk * kRowTableStride;
+            row[r] = s;
+            row[9 + r] = len;
+            if (len < 0 || len > kRowCap) bad = 1;
+        }
+    }
+    for (int d = 8; d >= 1; d >>= 1) bad |= __shfl_xor(bad, d, 16);
+    if (live && r == 0) {
+        int *row = table + (size_t)blk * kRowTableStride;
+        row[18] = bad ? 0 : 1;
+        row[19] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -348,6 +381,13 @@ int launch_reorder(Solver *s) {
     FSA_HIP(hipGetLastError());
     }
     std::swap(s->b.v_star, s->b.v_star_alt);
+    if (s->precision == FSA_PRECISION_F32) {
+        ScopedTimer t(s, "block_rows");
+        const int nblk = (s->n + kTunedBS - 1) / kTunedBS;
+        hipLaunchKernelGGL(block_rows_kernel, dim3((nblk * 16 + 255) / 256), dim3(256), 0, s->stream, s->pf, s->n,
+                           s->b.cellStart, s->b.sortedHash, s->b.blockRows);
+        FSA_HIP(hipGetLastError());
+    }
     if (s->slab) return launch_slab_keys(s);
     if (s->iisph) return launch_iisph_carry(s, out);
     return FSA_OK;

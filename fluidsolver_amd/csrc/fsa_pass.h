@@ -99,7 +99,11 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
-    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+    unsigned hlo = 0, hhi = 0;
+    if (!P.rows) {  // no row table: the rows follow from the cells of the block's first and last particle
+        hlo = (unsigned)sortedHash[b0];
+        hhi = (unsigned)sortedHash[b0 + nb - 1];
+    }
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     bool active = false;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
         if (!active) Policy::skip(A, P, index);
     }
     if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
     typename Policy::Self S;
     if (active) Policy::init(A, P, index, S);
     if (!staged) {

@@ -56,6 +56,7 @@ struct Buffers {
     int *cellStart = nullptr;    // num_cells + 1, exclusive prefix of cellCount; [num_cells] = particles in grid
     int *gridCellStart = nullptr;  // reference format (0xffffffff for an empty cell)
     int *gridCellEnd = nullptr;
+    int *blockRows = nullptr;    // row table of the tiled passes, rebuilt by every reorder (fp32)
     int *scanTmp = nullptr;
     int *undefBlockCount = nullptr;
     int *undefBlockStart = nullptr;

@@ -152,10 +152,15 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     const bool active = index < n;
-    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
-    // slab runs: a tile that lies entirely in the outer halo layer feeds nobody
-    if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
+    // the cells of the block's first and last particle: only needed without a row table, and in slab runs,
+    // where a tile that lies entirely in the outer halo layer feeds nobody
+    unsigned hlo = 0, hhi = 0;
+    if (!P.rows || P.nz != P.gres[2]) {
+        hlo = (unsigned)sortedHash[b0];
+        hhi = (unsigned)sortedHash[b0 + nb - 1];
+        if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
+    }
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -294,9 +299,14 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
-    const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
-    // slab runs: forces are only needed for the layers the solver owns
-    if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 0)) return;
+    // the cells of the block's first and last particle: only needed without a row table, and in slab runs,
+    // where forces are only needed for the layers the solver owns
+    unsigned hlo = 0, hhi = 0;
+    if (!P.rows || P.nz != P.gres[2]) {
+        hlo = (unsigned)sortedHash[b0];
+        hhi = (unsigned)sortedHash[b0 + nb - 1];
+        if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 0)) return;
+    }
 
     ForceSelf<float> S;
     S.p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     // a block without fluid particles (wall layers) has nothing to do
     if (!__syncthreads_or(active ? 1 : 0)) return;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi);
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
     if (active) {
         S.v = velMass[index];
         S.pterm = pd[index].x;

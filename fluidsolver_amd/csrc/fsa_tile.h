@@ -28,13 +28,47 @@ template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
     int staged;
 };
 
-// Block-uniform set-up.  Returns false when this block must take the per-particle path.
+// The row table of every block of kTunedBS consecutive sorted particles, computed once per sort and read by
+// every tiled pass until the next one: kRowTableStride ints per block = first particle of each of the 9 rows,
+// their lengths, and whether the block can be staged (every row in the grid and at most kRowCap long).
+constexpr int kRowTableStride = 20;
+
+__device__ __forceinline__ void block_row(const DevParams<float> &P, unsigned hlo, unsigned hhi, bool grid_ok, int r,
+                                          const int *__restrict__ cellStart, int &s, int &len) {
+    s = 0;
+    len = -1;
+    if (grid_ok) {
+        const int C = P.num_cells;
+        const int dz = r / 3 - 1, dy = r % 3 - 1;
+        const long long off = (long long)dy * P.gres[0] * P.nz + (long long)dz * P.gres[0];
+        long long a = (long long)hlo + off - 1, b = (long long)hhi + off + 2;
+        a = a < 0 ? 0 : (a > C ? C : a);
+        b = b < 0 ? 0 : (b > C ? C : b);
+        s = cellStart[a];
+        len = cellStart[b] - s;
+    }
+}
+
+// Block-uniform set-up.  Returns false when this block must take the per-particle path.  With a row table
+// (`rows` != nullptr) the block copies its entry; otherwise it derives the rows itself from the cells of its
+// first and last particle (hlo, hhi).
 template <int ROWCAP, typename Shared>
 __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, int nb,
                                            const int *__restrict__ cellStart,
                                            const int *__restrict__ sortedHash, Shared &sh, unsigned hlo,
-                                           unsigned hhi) {
+                                           unsigned hhi, const int *__restrict__ rows = nullptr) {
     const int tid = threadIdx.x;
+    if (rows) {
+        static_assert(ROWCAP == kRowCap, "the row table is built for kRowCap");
+        if (tid < 19) {
+            const int v = rows[(size_t)(b0 / kTunedBS) * kRowTableStride + tid];
+            if (tid < 9) sh.rowStartG[tid] = v;
+            else if (tid < 18) sh.rowLen[tid - 9] = v;
+            else sh.staged = v;
+        }
+        __syncthreads();
+        return sh.staged != 0;
+    }
     const int C = P.num_cells;
     const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
     if (tid < 9) {
