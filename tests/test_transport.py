@@ -23,3 +23,17 @@ def test_exchange_with_jumping_counts(world):
             if p.poll() is None:
                 p.kill()
     assert codes == [0] * world
+
+
+@pytest.mark.gpu
+def test_exchange_over_rccl_with_device_buffers():
+    """the "nccl" branch of the transport (device buffers handed to RCCL directly), one rank talking to itself"""
+    port = free_port()
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "transport_worker.py"), "--rank", "0", "--world", "1",
+                          "--port", str(port), "--rccl-self"])
+    try:
+        code = p.wait(timeout=100)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert code == 0

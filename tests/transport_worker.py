@@ -1,5 +1,10 @@
 """One rank of the record-transport test (started by test_transport.py): a chain of ranks exchanges
-record buffers whose sizes jump around, including zero and far beyond the agreed message size."""
+record buffers whose sizes jump around, including zero and far beyond the agreed message size.
+
+With --rccl-self a single rank on cuda:0 runs the same sequence over the "nccl" backend (RCCL) with itself
+as the peer: the device-buffer branch of the transport (no host staging, header written to and read from
+device memory, messages sliced out of the device buffers), which a box with one GPU cannot reach with two
+ranks."""
 import argparse
 import os
 import sys
@@ -28,7 +33,10 @@ def main():
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--rccl-self", action="store_true")
     a = ap.parse_args()
+    if a.rccl_self:
+        return rccl_self(a)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
     tr = slabs.NeighbourTransport(a.rank, a.world, torch.device("cpu"))
     peers = [p for p in (a.rank - 1, a.rank + 1) if 0 <= p < a.world]
@@ -49,6 +57,30 @@ def main():
             assert torch.equal(recv_buf[p][RB:(1 + want_cnt) * RB], want), (step, p)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def rccl_self(a):
+    assert a.world == 1 and a.rank == 0
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{a.port}", rank=0, world_size=1, device_id=dev)
+    tr = slabs.NeighbourTransport(0, 1, dev)
+    assert not tr.staged and tr.backend == "nccl"
+    cap = 8000
+    send_buf = torch.zeros((cap + 1) * RB, dtype=torch.uint8, device=dev)
+    recv_buf = {0: torch.zeros((cap + 1) * RB, dtype=torch.uint8, device=dev)}
+    side = torch.cuda.Stream(dev)  # not the default stream: the slab solver runs on a stream of its own
+    with torch.cuda.stream(side):
+        for step, cnt in enumerate(COUNTS):
+            want = payload(0, 0, step, cnt)
+            send_buf[RB:(1 + cnt) * RB] = want.to(dev)
+            got = tr.exchange({0: (send_buf, cnt)}, recv_buf, RB)
+            assert got[0] == cnt, (step, got[0], cnt)
+            assert torch.equal(recv_buf[0][RB:(1 + cnt) * RB].cpu(), want), step
+            recv_buf[0].zero_()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print("rccl-self ok")
 
 
 if __name__ == "__main__":
