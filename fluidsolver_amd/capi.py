@@ -28,7 +28,7 @@ EXPORTS = (
     "fsa_num_undef", "fsa_calc_hash", "fsa_sort_particle", "fsa_reorder_data_and_find_cell_start",
     "fsa_sort_particles", "fsa_compute_pressure", "fsa_compute_force", "fsa_advect",
     "fsa_rigid_particle_volume", "fsa_step", "fsa_readback_pos_color", "fsa_get_buffer", "fsa_set_buffer",
-    "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant",
+    "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant", "fsa_set_neighbour_lists",
     "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned", "fsa_slab_export_owned",
     "fsa_set_scene_has_rigid",
     "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
@@ -129,6 +129,7 @@ def load() -> C.CDLL:
         "fsa_timing_enable": [H, C.c_int], "fsa_timing_reset": [H],
         "fsa_timing_read": [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)],
         "fsa_set_variant": [H, C.c_int],
+        "fsa_set_neighbour_lists": [H, C.c_int],
         "fsa_slab_record_bytes": [H, C.POINTER(C.c_int)],
         "fsa_slab_pack": [H] + [C.POINTER(C.c_int)] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                            C.POINTER(C.c_int)],
@@ -325,6 +326,7 @@ class Solver:
     def synchronize(self): check(self.lib.fsa_synchronize(self._h))
     def set_stream(self, stream_ptr): check(self.lib.fsa_set_stream(self._h, C.c_void_p(stream_ptr)))
     def set_variant(self, v: int): check(self.lib.fsa_set_variant(self._h, int(v)))
+    def set_neighbour_lists(self, on: bool): check(self.lib.fsa_set_neighbour_lists(self._h, int(bool(on))))
 
     # -- DFSPH ------------------------------------------------------------------------
     def compute_density_alpha(self): check(self.lib.fsa_compute_density_alpha(self._h))

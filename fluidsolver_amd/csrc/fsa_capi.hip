@@ -113,7 +113,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.blockRows, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.nbList, b.nbCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -161,6 +161,7 @@ static void invalidate_order(Solver *s) {
     s->hash_valid = s->perm_valid = s->sorted_valid = false;
     s->index_table_valid = s->ref_cells_valid = false;
     s->pd_valid = false;
+    s->lists_valid = false;
 }
 
 }  // namespace fsa
@@ -498,6 +499,7 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
     s->sorted_valid = true;
     s->owned_from_sort = true;
     s->pd_valid = false;
+    s->lists_valid = false;
     s->hash_valid = false;  // hash[] described the previous order
     s->perm_valid = false;
     s->index_table_valid = false;
@@ -704,6 +706,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     const int c = s->cur;
     FSA_HIP(hipStreamSynchronize(s->stream));
     s->pd_valid = false;  // density, pressure, mass or viscosity may change under it
+    s->lists_valid = false;
     auto plain = [&](void *ddst, size_t expect) -> int {
         TRY(want(expect));
         if (bytes) FSA_HIP(hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice));
@@ -1104,6 +1107,14 @@ int fsa_set_variant(fsa_solver *hs, int variant) {
     if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
     if (variant < 0 || variant > 2) return fail(FSA_ERR_INVALID, "unknown variant %d", variant);
     s->variant = variant;
+    return FSA_OK;
+}
+
+int fsa_set_neighbour_lists(fsa_solver *hs, int enabled) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
+    s->use_lists = enabled != 0;
+    s->lists_valid = false;
     return FSA_OK;
 }
 

@@ -375,13 +375,14 @@ int launch_density_rigid_tuned(Solver *s) {
 
 int launch_density_alpha(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    if (use_tiles(s)) return launch_tuned<AlphaPolicy<float>>(s, "density_alpha");
+    if (use_tiles(s)) return launch_tuned<AlphaPolicy<float>>(s, "density_alpha", true);
     DF_GENERIC(AlphaPolicy<T>, "density_alpha");
     return FSA_OK;
 }
 
 int launch_non_pressure_force(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    // (no lists: wall particles count beyond the support, solver/sph_kernel_impl.cuh:315-352)
     if (use_tiles(s)) return launch_tuned<NpfPolicy<float>>(s, "non_pressure_force");
     DF_GENERIC(NpfPolicy<T>, "non_pressure_force");
     return FSA_OK;
@@ -392,8 +393,8 @@ int launch_solve_density_stiff(Solver *s) {
     if (use_tiles(s)) {
         int rc = pack_vstar_mass(s);
         if (rc) return rc;
-        if (use_fast(s)) return launch_tuned<StiffPolicy<float, true, true, true>>(s, "density_stiff");
-        return launch_tuned<StiffPolicy<float, true, true>>(s, "density_stiff");
+        if (use_fast(s)) return launch_tuned<StiffPolicy<float, true, true, true>>(s, "density_stiff", true);
+        return launch_tuned<StiffPolicy<float, true, true>>(s, "density_stiff", true);
     }
     // (these policy names carry commas, which a macro argument cannot: hence the alias macro)
 #define FSA_POLICY StiffPolicy<T, true, false>
@@ -407,8 +408,8 @@ int launch_solve_divergence_stiff(Solver *s) {
     if (use_tiles(s)) {
         int rc = pack_vstar_mass(s);
         if (rc) return rc;
-        if (use_fast(s)) return launch_tuned<StiffPolicy<float, false, true, true>>(s, "divergence_stiff");
-        return launch_tuned<StiffPolicy<float, false, true>>(s, "divergence_stiff");
+        if (use_fast(s)) return launch_tuned<StiffPolicy<float, false, true, true>>(s, "divergence_stiff", true);
+        return launch_tuned<StiffPolicy<float, false, true>>(s, "divergence_stiff", true);
     }
 #define FSA_POLICY StiffPolicy<T, false, false>
     DF_GENERIC(FSA_POLICY, "divergence_stiff");
@@ -427,8 +428,8 @@ int launch_apply_pstiff(Solver *s) {
                                (const float4 *)s->b.velMass[s->cur], (float2 *)s->b.pd);
             FSA_HIP(hipGetLastError());
         }
-        if (use_fast(s)) return launch_tuned<ApplyPolicy<float, true, true>>(s, "apply_pstiff");
-        return launch_tuned<ApplyPolicy<float, true>>(s, "apply_pstiff");
+        if (use_fast(s)) return launch_tuned<ApplyPolicy<float, true, true>>(s, "apply_pstiff", true);
+        return launch_tuned<ApplyPolicy<float, true>>(s, "apply_pstiff", true);
     }
 #define FSA_POLICY ApplyPolicy<T, false>
     DF_GENERIC(FSA_POLICY, "apply_pstiff");
@@ -439,6 +440,7 @@ int launch_apply_pstiff(Solver *s) {
 int launch_update_position(Solver *s) {
     if (s->n == 0) return FSA_OK;
     ScopedTimer t(s, "update_position");
+    s->lists_valid = false;  // positions move
     DF_DISPATCH(update_position_kernel, (Vec4<T> *)s->b.posType[s->cur], (const Vec3<T> *)s->b.v_star);
     return FSA_OK;
 }

@@ -583,7 +583,7 @@ static bool use_fast(const Solver *s) { return use_tiles(s) && s->variant >= 2; 
 #define IISPH_PASS(PolicyName, tag)                                              \
     do {                                                                         \
         if (s->n == 0) return FSA_OK;                                            \
-        if (use_tiles(s)) return launch_tuned<PolicyName<float>>(s, tag);        \
+        if (use_tiles(s)) return launch_tuned<PolicyName<float>>(s, tag, true);  \
         DF_GENERIC(PolicyName<T>, tag);                                          \
         return FSA_OK;                                                           \
     } while (0)
@@ -611,7 +611,7 @@ int launch_iisph_dijpjl(Solver *s) {
                                (const float *)s->b.pressure, (const float *)s->b.density, (float *)s->b.pd);
             FSA_HIP(hipGetLastError());
         }
-        return launch_tuned<IisphDijpjlFastPolicy>(s, "iisph_dijpjl");
+        return launch_tuned<IisphDijpjlFastPolicy>(s, "iisph_dijpjl", true);
     }
     IISPH_PASS(IisphDijpjlPolicy, "iisph_dijpjl");
 }
@@ -619,9 +619,13 @@ int launch_iisph_pressure_force(Solver *s) { IISPH_PASS(IisphPressureForcePolicy
 
 int launch_iisph_new_pressure(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    if (use_tiles(s)) {
+        const int rc = ensure_lists(s);
+        if (rc) return rc;
+    }
     {
         ScopedTimer t(s, "iisph_new_pressure");
-        const int unit = kXcds << xcd_run_log();
+        int rc = FSA_OK;
         if (use_fast(s)) {
             hipLaunchKernelGGL(iisph_pack_cvec_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
                                (const Vec3<float> *)s->b.dii, (const Vec3<float> *)s->b.dijpjl,
@@ -629,17 +633,11 @@ int launch_iisph_new_pressure(Solver *s) {
                                (float4 *)s->b.aux4);
             PassArrays<float> A = arrays_of<float>(s);
             A.pressureOut = (float *)s->b.pressure_alt;
-            const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-            hipLaunchKernelGGL((tuned_pass_kernel<IisphNewPressureFastPolicy, kTunedBS, kRowCap, kQueueDf>), dim3(nb),
-                               dim3(kTunedBS), 0, s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash,
-                               xcd_run_log());
+            rc = run_tiled<IisphNewPressureFastPolicy>(s, A, true);
         } else if (use_tiles(s)) {
             PassArrays<float> A = arrays_of<float>(s);
             A.pressureOut = (float *)s->b.pressure_alt;
-            const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-            hipLaunchKernelGGL((tuned_pass_kernel<IisphNewPressurePolicy<float>, kTunedBS, kRowCap, kQueueDf>), dim3(nb),
-                               dim3(kTunedBS), 0, s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash,
-                               xcd_run_log());
+            rc = run_tiled<IisphNewPressurePolicy<float>>(s, A, true);
         } else if (s->precision == FSA_PRECISION_F32) {
             PassArrays<float> A = arrays_of<float>(s);
             A.pressureOut = (float *)s->b.pressure_alt;
@@ -651,6 +649,7 @@ int launch_iisph_new_pressure(Solver *s) {
             hipLaunchKernelGGL((generic_pass_kernel<double, IisphNewPressurePolicy<double>>), dim3(blocks_for(s->n)),
                                dim3(kBlock), 0, s->stream, s->pd, s->n, A, s->b.cellStart);
         }
+        if (rc) return rc;
         FSA_HIP(hipGetLastError());
     }
     std::swap(s->b.pressure, s->b.pressure_alt);
@@ -660,6 +659,7 @@ int launch_iisph_new_pressure(Solver *s) {
 int launch_iisph_integrate(Solver *s) {
     if (s->n == 0) return FSA_OK;
     ScopedTimer t(s, "iisph_integrate");
+    s->lists_valid = false;  // positions move
     const int c = s->cur;
     DF_DISPATCH(iisph_integrate_kernel, (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
                 (const Vec3<T> *)s->b.v_star, (const Vec3<T> *)s->b.pressureForce);

@@ -1,0 +1,139 @@
+// Neighbour lists for the passes that repeat between two sorts (the relaxation rounds of the IISPH and DFSPH
+// steps run 20-odd neighbour passes over the same positions): the cull of the tiled pass kernel
+// (fsa_pass.h) is done once, its hits are written out, and the passes replay them (list_pass_kernel).
+//
+// The list of a particle holds, in the order of the reference's 27-cell walk (z, y, x cell loops, ascending
+// index inside a cell; solver/sph_kernel_impl.cuh:255-260), every particle of any type whose fused squared
+// distance is below the support radius squared times 1.000002, itself included, as 16-bit entries relative to
+// the row table of its block.  Layout and limits: fsa_tile.h.
+#include <type_traits>
+
+#include "fsa_pair.h"
+#include "fsa_solver.h"
+#include "fsa_tile.h"
+
+namespace fsa {
+
+template <int BS, int ROWCAP, int Q, int K>
+__global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int n,
+                                                        const float4 *__restrict__ posType,
+                                                        const int *__restrict__ cellStart,
+                                                        const int *__restrict__ sortedHash,
+                                                        unsigned short *__restrict__ list,
+                                                        unsigned short *__restrict__ counts, int xcd_log) {
+    using Shared = RowShared<BS, ROWCAP, false>;
+    __shared__ Shared sh;
+    __shared__ unsigned short queue[Q * BS];
+    const int tid = threadIdx.x;
+    const int b0 = xcd_block(xcd_log) * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int nb = min(BS, n - b0);
+    const int index = b0 + tid;
+    const bool active = index < n;
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, 0u, 0u, P.rows);
+    if (!staged) {  // the passes walk the cells for this block
+        if (active) counts[index] = (unsigned short)kListOverflow;
+        return;
+    }
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) pi = posType[index];
+    const float sr2c = P.sr * P.sr * 1.000002f;
+    const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
+    unsigned short *const q = queue + tid;
+    unsigned short *const L = list + ((size_t)(b0 / BS) * (K / 4) * BS + tid) * 4;
+    int cnt = 0, total = 0;
+    auto flush = [&]() {
+        for (int s = 0; wave_any(s < cnt); s++) {
+            const int slot = total + s;
+            if (s < cnt && slot < K) L[(size_t)(slot >> 2) * (BS * 4) + (slot & 3)] = q[s * BS];
+        }
+        total += cnt;
+        cnt = 0;
+    };
+
+    float4 e0, e1;
+    int lj, le, nlj = 0, nle = 0;
+    row_fetch<BS, ROWCAP, false>(sh, 0, posType, e0, e1);
+    lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+    row_store<BS, ROWCAP, false>(sh, 0, e0, e1);
+    __syncthreads();
+    for (int r = 0; r < 9; r++) {
+        const int buf = r & 1;
+        if (r + 1 < 9) {  // in flight during the cull below
+            row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e0, e1);
+            lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+        }
+        const int tag = r << 9;
+        // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
+        auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            float d2[kChunk];
+            group_d2<true>(sh.x[buf][g], sh.y[buf][g], sh.z[buf][g], pi.x, pi.y, pi.z, d2);
+            const int etag = tag | (g * kChunk);
+#pragma unroll
+            for (int u = 0; u < kChunk; u++) {
+                q[cnt * BS] = (unsigned short)(etag + u);  // a miss is overwritten by the next store
+                cnt += (d2[u] < sr2c && (!MASKED || (u >= lo && u < hi))) ? 1 : 0;
+            }
+        };
+        const bool has = lj < le;
+        int base = lj & ~(kChunk - 1);
+        if (wave_any(has)) {  // first group of the range
+            cull_group(has ? base / kChunk : Shared::kPad, lj - base, le - base, std::true_type());
+            if (wave_any(cnt > Q - kChunk)) flush();
+        }
+        base = has ? base + kChunk : le;
+        while (wave_any(base + kChunk <= le)) {  // whole groups
+            const bool go = base + kChunk <= le;
+            cull_group(go ? base / kChunk : Shared::kPad, 0, kChunk, std::false_type());
+            base += go ? kChunk : 0;
+            if (wave_any(cnt > Q - kChunk)) flush();
+        }
+        if (wave_any(base < le)) {  // last group of the range
+            const int rem = le - base;
+            cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
+            if (wave_any(cnt > Q - kChunk)) flush();
+        }
+        if (r + 1 < 9) {
+            row_store<BS, ROWCAP, false>(sh, buf ^ 1, e0, e1);
+            lj = nlj;
+            le = nle;
+            __syncthreads();
+        }
+    }
+    flush();
+    if (active) counts[index] = (unsigned short)(total > K ? kListOverflow : total);
+}
+
+constexpr int kQueueL = 16;
+
+int ensure_lists(Solver *s) {
+    if (!s->use_lists || s->lists_valid || s->n == 0) return FSA_OK;
+    if (s->precision != FSA_PRECISION_F32 || !s->sorted_valid || !s->pf.rows) {
+        s->lists_valid = false;
+        return FSA_OK;  // the passes use the tiles
+    }
+    if (!s->b.nbList) {  // sized for the solver's capacity, kept until fsa_destroy
+        const size_t blocks = ((size_t)s->capacity + kTunedBS - 1) / kTunedBS + 1;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, blocks * kListSlots * kTunedBS * sizeof(unsigned short));
+        if (e != hipSuccess)
+            return fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour lists (%zu blocks) failed: %s", blocks,
+                        hipGetErrorString(e));
+        s->b.nbList = (unsigned short *)p;
+        e = hipMalloc(&p, blocks * kTunedBS * sizeof(unsigned short));
+        if (e != hipSuccess) return fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour counts failed: %s", hipGetErrorString(e));
+        s->b.nbCount = (unsigned short *)p;
+    }
+    ScopedTimer t(s, "list_build");
+    const int unit = kXcds << xcd_run_log();
+    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    hipLaunchKernelGGL((list_build_kernel<kTunedBS, kRowCap, kQueueL, kListSlots>), dim3(nb), dim3(kTunedBS), 0,
+                       s->stream, s->pf, s->n, (const float4 *)s->b.posType[s->cur], s->b.cellStart, s->b.sortedHash,
+                       s->b.nbList, s->b.nbCount, xcd_run_log());
+    FSA_HIP(hipGetLastError());
+    s->lists_valid = true;
+    return FSA_OK;
+}
+
+}  // namespace fsa

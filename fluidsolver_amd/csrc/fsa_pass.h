@@ -235,6 +235,78 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
     if (active) Policy::finish(A, P, index, S);
 }
 
+// The list flavour (fp32): the hits of every lane were recorded once after the sort (list_build_kernel in
+// fsa_lists.hip: the cull of the tiled kernel with the same slack, every particle type, entries in the same
+// order) and are replayed here, so a pass costs the gathers and the policy's arithmetic only.  Same `pair`
+// calls in the same order as the tiled kernel: same bits.  Blocks the row table marks as not staged, and lanes
+// whose list overflowed, walk the cells.
+template <typename Policy, int BS, int K>
+__global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n, PassArrays<float> A,
+                                                       const int *__restrict__ cellStart,
+                                                       const unsigned short *__restrict__ list,
+                                                       const unsigned short *__restrict__ counts, int xcd_log) {
+    __shared__ int rowStartG[9];
+    __shared__ int stagedFlag;
+    const int tid = threadIdx.x;
+    const int b0 = xcd_block(xcd_log) * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int index = b0 + tid;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool active = false;
+    if (index < n) {
+        pi = A.posType[index];
+        active = Policy::wants(unpack_int(pi.w));
+        if (!active) Policy::skip(A, P, index);
+    }
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
+    if (tid < 9) rowStartG[tid] = P.rows[(size_t)(b0 / BS) * kRowTableStride + tid];
+    if (tid == 18) stagedFlag = P.rows[(size_t)(b0 / BS) * kRowTableStride + 18];
+    __syncthreads();
+    typename Policy::Self S;
+    if (active) Policy::init(A, P, index, S);
+    if (!stagedFlag) {
+        if (active) {
+            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+            Policy::finish(A, P, index, S);
+        }
+        return;
+    }
+    int cnt = active ? (int)counts[index] : 0;
+    const bool overflow = cnt == kListOverflow;
+    if (overflow) cnt = 0;
+    const int safe = index < n ? index : 0;
+    // four consecutive slots of a lane are one 8-byte word; a wavefront reads 512 contiguous bytes per word
+    const uint2 *const L = reinterpret_cast<const uint2 *>(list) + (size_t)(b0 / BS) * (K / 4) * BS + tid;
+    uint2 cur = cnt > 0 ? L[0] : make_uint2(0u, 0u);
+    for (int s = 0; wave_any(s < cnt); s += 4) {
+        const uint2 nxt = s + 4 < cnt ? L[(size_t)(s / 4 + 1) * BS] : make_uint2(0u, 0u);
+        const unsigned e[4] = {cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16};
+        int j[4];
+        float4 pj[4];
+        typename Policy::Nb nbr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) j[u] = s + u < cnt ? rowStartG[e[u] >> 9] + (int)(e[u] & 511u) : safe;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            pj[u] = A.posType[j[u]];
+            nbr[u] = Policy::load(A, j[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (s + u < cnt) {
+                const int tj = unpack_int(pj[u].w);
+                if (Policy::reach(tj) != 0) {
+                    const float xx = pi.x - pj[u].x, xy = pi.y - pj[u].y, xz = pi.z - pj[u].z;
+                    const float d2 = xx * xx + xy * xy + xz * xz;
+                    Policy::pair(A, P, S, j[u] == index, tj, j[u], xx, xy, xz, d2, pj[u], nbr[u]);
+                }
+            }
+        cur = nxt;
+    }
+    if (overflow) generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+    if (active) Policy::finish(A, P, index, S);
+}
+
 static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 #define DF_DISPATCH(kernel, ...)                                                                                  \
@@ -285,15 +357,28 @@ constexpr int kQueueDf = 48;  // 16-bit slots, as in the WCSPH force pass
 
 static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F32 && s->variant >= 1; }
 
-// Policy<float> through the tiled kernel
-template <typename Policy> static int launch_tuned(Solver *s, const char *tag) {
-    ScopedTimer t(s, tag);
+// Policy<float> over arrays A through the tiled kernel, or, with `lists`, through the recorded neighbour lists
+// (worth it for passes that run many times per sort; the policy must not reach any type beyond the support).
+template <typename Policy> static int run_tiled(Solver *s, const PassArrays<float> &A, bool lists) {
     const int unit = kXcds << xcd_run_log();
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-    hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
-                       s->stream, s->pf, s->n, arrays_of<float>(s), s->b.cellStart, s->b.sortedHash, xcd_run_log());
+    if (lists && s->use_lists && s->lists_valid)
+        hipLaunchKernelGGL((list_pass_kernel<Policy, kTunedBS, kListSlots>), dim3(nb), dim3(kTunedBS), 0, s->stream,
+                           s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, xcd_run_log());
+    else
+        hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
+                           s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, xcd_run_log());
     FSA_HIP(hipGetLastError());
     return FSA_OK;
+}
+
+template <typename Policy> static int launch_tuned(Solver *s, const char *tag, bool lists = false) {
+    if (lists) {
+        const int rc = ensure_lists(s);
+        if (rc) return rc;
+    }
+    ScopedTimer t(s, tag);
+    return run_tiled<Policy>(s, arrays_of<float>(s), lists);
 }
 
 // Policy<T> through the one-thread-per-particle kernel, either precision

@@ -57,6 +57,8 @@ struct Buffers {
     int *gridCellStart = nullptr;  // reference format (0xffffffff for an empty cell)
     int *gridCellEnd = nullptr;
     int *blockRows = nullptr;    // row table of the tiled passes, rebuilt by every reorder (fp32)
+    unsigned short *nbList = nullptr;   // recorded neighbour lists (allocated on first use), see fsa_tile.h
+    unsigned short *nbCount = nullptr;  // entries per particle
     int *scanTmp = nullptr;
     int *undefBlockCount = nullptr;
     int *undefBlockStart = nullptr;
@@ -97,6 +99,8 @@ struct Solver {
     bool ref_cells_valid = false;
     bool pd_valid = false;  // pd[] matches density / pressure / mass of the current arrays ...
     bool pd_fast = false;   // ... in the fast flavour's layout
+    bool use_lists = true;      // passes that repeat between two sorts replay recorded neighbour lists
+    bool lists_valid = false;   // nbList / nbCount describe the current arrays and positions
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
@@ -161,6 +165,7 @@ int launch_iisph_new_pressure(Solver *s);
 int launch_iisph_pressure_force(Solver *s);
 int launch_iisph_integrate(Solver *s);
 int launch_mean_error(Solver *s, double *out);  // synchronises
+int ensure_lists(Solver *s);  // builds the neighbour lists if they are enabled and stale
 int launch_density_tuned(Solver *s);
 int launch_density_rigid_tuned(Solver *s);
 int launch_force_tuned(Solver *s);

@@ -33,6 +33,13 @@ template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
 // their lengths, and whether the block can be staged (every row in the grid and at most kRowCap long).
 constexpr int kRowTableStride = 20;
 
+// Recorded neighbour lists: at most kListSlots entries per particle, 16 bits each (row << 9 | index in the row,
+// as in the hit queues), four consecutive slots of a lane packed into one 8-byte word:
+//   word index = (block * kListSlots / 4 + slot / 4) * kTunedBS + lane
+// and one 16-bit count per particle, kListOverflow when the list did not fit (or the block is not staged).
+constexpr int kListSlots = 64;
+constexpr int kListOverflow = 0xffff;
+
 __device__ __forceinline__ void block_row(const DevParams<float> &P, unsigned hlo, unsigned hhi, bool grid_ok, int r,
                                           const int *__restrict__ cellStart, int &s, int &len) {
     s = 0;

@@ -287,6 +287,15 @@ int fsa_timing_read(fsa_solver *s, fsa_kernel_time *out, int cap, int *count);
  *      DFSPH and IISPH passes run the exact arithmetic in every variant. */
 int fsa_set_variant(fsa_solver *s, int variant);
 
+/* Recorded neighbour lists (fp32, variants 1 and 2; no counterpart in the reference, which walks the 27
+ * cells in every kernel).  The IISPH and DFSPH steps run 20-odd neighbour passes between two sorts over the
+ * same positions: with lists enabled (the default) the first such pass after a sort records, per particle
+ * and in the reference's neighbour order, every particle within the support radius, and the passes replay
+ * that list instead of searching again.  Same pair arithmetic in the same order: results are bit for bit
+ * those of the searching kernels.  Costs 128 bytes of device memory per particle of the solver's capacity,
+ * allocated when first used.  The WCSPH step (two passes per sort) does not use them. */
+int fsa_set_neighbour_lists(fsa_solver *s, int enabled);
+
 /* ---- z-slab decomposition: one solver per GPU ---------------------------
  *
  * The reference runs on one device; these entry points have no counterpart in it.  They split the

@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dims", type=int, nargs=3, default=[128, 64, 128])
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--variant", type=int, default=2)
+ap.add_argument("--no-lists", action="store_true", help="search in every pass instead of replaying recorded lists")
 a = ap.parse_args()
 sc = scenes.dam_break(*a.dims, wall_type=scenes.TYPE_RIGID)
 sc["mass"][sc["type"] == scenes.TYPE_RIGID] = scenes.rigid_mass(sc["params"]["spacing"], sc["params"]["restdensity"])
@@ -16,6 +17,7 @@ sc["params"] = dict(sc["params"], viscosity=0.05, **scenes.IISPH_PARAMS)
 p = capi.make_params(capi.PRECISION_F32, **sc["params"])
 s = capi.Solver(p, len(sc["pos"]))
 s.set_variant(a.variant)
+s.set_neighbour_lists(not a.no_lists)
 s.upload(sc)
 s.setup_iisph()
 s.step_iisph(3)
@@ -29,7 +31,7 @@ kt = s.timing_read()
 import numpy as np
 fl = s.get("type") == 0
 print(json.dumps({"scene": a.dims, "particles": len(sc["pos"]), "fluid": sc["n_fluid"], "variant": a.variant,
-                  "ms_per_step": wall / a.steps * 1e3,
+                  "neighbour_lists": not a.no_lists, "ms_per_step": wall / a.steps * 1e3,
                   "particle_steps_per_s": sc["n_fluid"] * a.steps / wall,
                   "max_density": float(s.get("density")[fl].max()), "finite": bool(np.isfinite(s.get("pos")).all()),
                   "out_of_grid": s.num_undef(), "max_speed": float(np.abs(s.get("vel")[fl]).max()),
