@@ -84,6 +84,7 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.own_lo = -(1 << 30);
     d.own_hi = 1 << 30;
     d.rows = nullptr;
+    d.big = nullptr;
 }
 
 static int check_params(const fsa_params *p) {
@@ -113,7 +114,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.blockRows, b.nbList, b.nbCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.nbList, b.nbCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -288,6 +289,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.gridCellStart, C * sizeof(int), true);
     ALLOC(b.gridCellEnd, C * sizeof(int), true);
     ALLOC(b.blockRows, (nblocks + 8) * 20 * sizeof(int), true);
+    ALLOC(b.bigBlocks, (nblocks + 8) * sizeof(int), true);
     ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
     ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);
     ALLOC(b.undefBlockStart, (nblocks + 8) * sizeof(int), true);
@@ -316,6 +318,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
         return rc;
     }
     s->pf.rows = s->b.blockRows;
+    s->pf.big = s->b.bigBlocks;
     *out = reinterpret_cast<fsa_solver *>(s);
     return FSA_OK;
 }
@@ -346,6 +349,7 @@ int fsa_copy_param_to_device(fsa_solver *hs, const fsa_params *p) {
     s->pf.own_lo = s->pd.own_lo = own_lo;
     s->pf.own_hi = s->pd.own_hi = own_hi;
     s->pf.rows = s->b.blockRows;
+    s->pf.big = s->b.bigBlocks;
     invalidate_order(s);
     return FSA_OK;
 }
@@ -625,6 +629,18 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
         const void *table = k == "color" ? s->b.color : k == "normal" ? s->b.normal : (const void *)s->b.group;
         TRY(launch_gather_by_uid(s, table, st.d, s->n, (int)words));
         return copy_out(s, st.d, dst, bytes);
+    }
+    if (k == "neighbourCount") {  // entries of each particle's recorded list (builds the lists if stale); -1 = walks the cells
+        TRY(want(N * sizeof(int)));
+        if (!s->sorted_valid || s->precision != FSA_PRECISION_F32 || !s->use_lists)
+            return fail(FSA_ERR_INVALID, "neighbourCount needs a sorted fp32 state with lists enabled");
+        TRY(ensure_lists(s));
+        std::vector<unsigned short> h(N);
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        if (N) FSA_HIP(hipMemcpy(h.data(), s->b.nbCount, N * sizeof(unsigned short), hipMemcpyDeviceToHost));
+        int *out = (int *)dst;
+        for (size_t i = 0; i < N; i++) out[i] = h[i] == 0xffff ? -1 : (int)h[i];
+        return FSA_OK;
     }
     if (k == "force") { TRY(want(N * 3 * R)); return copy_out(s, s->b.force, dst, bytes); }
     if (k == "v_star") { TRY(want(N * 3 * R)); return copy_out(s, s->b.v_star, dst, bytes); }

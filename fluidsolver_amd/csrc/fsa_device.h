@@ -61,6 +61,7 @@ template <typename T> struct DevParams {
     int own_lo, own_hi;
     // fp32 solvers: the row table of the tiled passes for the current sorted order (see fsa_tile.h), else null
     const int *rows;
+    const int *big;   // [0] = number of blocks with large tiles, then their ids (fsa_tile.h); rebuilt with `rows`
 };
 
 __device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }

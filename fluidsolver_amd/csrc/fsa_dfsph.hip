@@ -190,7 +190,10 @@ template <typename T, bool PACKED, bool FAST = false> struct ApplyPolicy {
         S.fx = S.fy = S.fz = 0;
     }
     static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
-        if (PACKED) return Nb{A.aux2[2 * (size_t)j], A.aux2[2 * (size_t)j + 1]};
+        if constexpr (PACKED) {  // one 8-byte load
+            const float2 v = reinterpret_cast<const float2 *>(A.aux2)[j];
+            return Nb{(T)v.x, (T)v.y};
+        }
         return Nb{A.pstiffIn[j] / A.density[j], reinterpret_cast<const T *>(A.velMass)[4 * (size_t)j + 3]};
     }
     static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int tj,
@@ -365,12 +368,7 @@ int launch_density_rigid_tuned(Solver *s) {
     ScopedTimer t(s, "density");
     PassArrays<float> A = arrays_of<float>(s);
     A.pstiffOut = (float *)s->b.pressure;
-    const int unit = kXcds << xcd_run_log();
-    const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-    hipLaunchKernelGGL((tuned_pass_kernel<DensityRigidPolicy<float>, kTunedBS, kRowCap, kQueueDf>), dim3(nb),
-                       dim3(kTunedBS), 0, s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, xcd_run_log());
-    FSA_HIP(hipGetLastError());
-    return FSA_OK;
+    return run_tiled<DensityRigidPolicy<float>>(s, A, false);
 }
 
 int launch_density_alpha(Solver *s) {

@@ -281,12 +281,12 @@ __global__ __launch_bounds__(kBlock) void index_table_kernel(int n, const int *_
 // 16 lanes per block entry: lanes 0..8 look up one row each, the verdict is folded over the 16 lanes
 __global__ __launch_bounds__(256) void block_rows_kernel(DevParams<float> P, int n, const int *__restrict__ cellStart,
                                                          const int *__restrict__ sortedHash,
-                                                         int *__restrict__ table) {
+                                                         int *__restrict__ table, int *__restrict__ big) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int blk = gid >> 4, r = gid & 15;
     const int nblk = (n + kTunedBS - 1) / kTunedBS;
     const bool live = blk < nblk;
-    int bad = 0;
+    int bad = 0, longest = 0;
     if (live) {
         const int b0 = blk * kTunedBS, nb = min(kTunedBS, n - b0);
         const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
@@ -298,14 +298,20 @@ __global__ __launch_bounds__(256) void block_rows_kernel(DevParams<float> P, int
             int *row = table + (size_t)blk * kRowTableStride;
             row[r] = s;
             row[9 + r] = len;
-            if (len < 0 || len > kRowCap) bad = 1;
+            if (len < 0 || len > kRowCapBig) bad = 1;
+            longest = len;
         }
     }
-    for (int d = 8; d >= 1; d >>= 1) bad |= __shfl_xor(bad, d, 16);
+    for (int d = 8; d >= 1; d >>= 1) {
+        bad |= __shfl_xor(bad, d, 16);
+        longest = max(longest, __shfl_xor(longest, d, 16));
+    }
     if (live && r == 0) {
         int *row = table + (size_t)blk * kRowTableStride;
-        row[18] = bad ? 0 : 1;
+        const int cls = bad ? 0 : (longest <= kRowCap ? 1 : 2);
+        row[18] = cls;
         row[19] = 0;
+        if (cls == 2) big[1 + atomicAdd(&big[0], 1)] = blk;  // any order: the blocks are independent
     }
 }
 
@@ -384,8 +390,9 @@ int launch_reorder(Solver *s) {
     if (s->precision == FSA_PRECISION_F32) {
         ScopedTimer t(s, "block_rows");
         const int nblk = (s->n + kTunedBS - 1) / kTunedBS;
+        FSA_HIP(hipMemsetAsync(s->b.bigBlocks, 0, sizeof(int), s->stream));
         hipLaunchKernelGGL(block_rows_kernel, dim3((nblk * 16 + 255) / 256), dim3(256), 0, s->stream, s->pf, s->n,
-                           s->b.cellStart, s->b.sortedHash, s->b.blockRows);
+                           s->b.cellStart, s->b.sortedHash, s->b.blockRows, s->b.bigBlocks);
         FSA_HIP(hipGetLastError());
     }
     if (s->slab) return launch_slab_keys(s);

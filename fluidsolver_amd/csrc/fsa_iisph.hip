@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void block_sum_kernel(int n, const T *__res
 // Same sums over the same neighbours, arranged for speed: hardware reciprocal square root and fused
 // multiply-adds, no double arithmetic per pair, and everything a pass needs of a neighbour gathered from one
 // packed record that a small kernel writes first:
-//   CalcDIJPJL        reads  pterm_j = p_j / rho_j^2
+//   CalcDIJPJL        reads  {x_j, p_j / rho_j^2}
 //   CalcNewPressure   reads  {d_jj p_j + dijpjl_j, restDensity_j}
 // About 1e-6 relative away from the exact flavour per term.
 __device__ __forceinline__ float grad_scale_fast(float d2, float inv_h, float kgrad) {
@@ -478,13 +478,17 @@ __device__ __forceinline__ float grad_scale_fast(float d2, float inv_h, float kg
     return (d2 > 0.0f && q < 2.0f) ? df * kgrad * rinv : 0.0f;
 }
 
-__global__ __launch_bounds__(kBlock) void iisph_pack_pterm_kernel(int n, const float *__restrict__ pressure,
+// {x, y, z, p / rho^2}: all CalcDIJPJL reads of a neighbour.  The last entry is 0 for a particle that does not
+// count (rigid ones, whose density is never set): its term then adds an exact zero.
+__global__ __launch_bounds__(kBlock) void iisph_pack_pterm_kernel(int n, const float4 *__restrict__ posType,
+                                                                  const float *__restrict__ pressure,
                                                                   const float *__restrict__ density,
-                                                                  float *__restrict__ pterm) {
+                                                                  float4 *__restrict__ rec) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    const float4 p = posType[i];
     const float d = density[i];
-    pterm[i] = pressure[i] / d / d;  // unused (and possibly not finite) for rigid particles, whose density is never set
+    rec[i] = make_float4(p.x, p.y, p.z, fluid_like(unpack_int(p.w)) ? pressure[i] / d / d : 0.0f);
 }
 
 __global__ __launch_bounds__(kBlock) void iisph_pack_cvec_kernel(int n, const Vec3<float> *__restrict__ dii,
@@ -502,9 +506,15 @@ __global__ __launch_bounds__(kBlock) void iisph_pack_cvec_kernel(int n, const Ve
 
 struct IisphDijpjlFastPolicy {
     using T = float;
+    // (what the search admits; a record that does not count carries a zero instead of being skipped)
     static __device__ __forceinline__ int reach(int tj) { return fluid_like(tj) ? 1 : 0; }
     struct Self { T ax, ay, az, mass, inv_h; };
-    struct Nb { T pterm; };
+    static constexpr bool kPosInNb = true;
+    static constexpr bool kDeepReplay = true;
+    struct Nb {
+        Vec4<T> r;  // {x, y, z, pterm or 0}
+        __device__ __forceinline__ Vec4<T> pos() const { return make_float4(r.x, r.y, r.z, 0.0f); }  // type bits: fluid
+    };
     static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
     static __device__ __forceinline__ void skip(const PassArrays<T> &, const DevParams<T> &, int) {}
     static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
@@ -512,11 +522,11 @@ struct IisphDijpjlFastPolicy {
         S.mass = A.velMass[index].w;
         S.inv_h = 2.0f / P.sr;
     }
-    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.aux2[j]}; }
-    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.aux4[j]}; }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int,
                                                 int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
-        if (d2 >= P.sr * P.sr || !fluid_like(tj)) return;
-        const T w = grad_scale_fast(d2, S.inv_h, P.kernel_cubic_gradient) * nb.pterm;
+        if (d2 >= P.sr * P.sr) return;
+        const T w = grad_scale_fast(d2, S.inv_h, P.kernel_cubic_gradient) * nb.r.w;
         S.ax = __builtin_fmaf(xx, w, S.ax);
         S.ay = __builtin_fmaf(xy, w, S.ay);
         S.az = __builtin_fmaf(xz, w, S.az);
@@ -529,6 +539,7 @@ struct IisphDijpjlFastPolicy {
 
 struct IisphNewPressureFastPolicy {
     using T = float;
+    static constexpr bool kDeepReplay = true;
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
     struct Self { T lll, p_i, mass, rd, k1, inv_h; Vec3<T> dijpjl; };
     struct Nb { Vec4<T> c; };
@@ -606,9 +617,9 @@ int launch_iisph_dijpjl(Solver *s) {
     if (use_fast(s)) {
         {
             ScopedTimer t(s, "iisph_pack_pterm");
-            s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
             hipLaunchKernelGGL(iisph_pack_pterm_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
-                               (const float *)s->b.pressure, (const float *)s->b.density, (float *)s->b.pd);
+                               (const float4 *)s->b.posType[s->cur], (const float *)s->b.pressure,
+                               (const float *)s->b.density, (float4 *)s->b.aux4);
             FSA_HIP(hipGetLastError());
         }
         return launch_tuned<IisphDijpjlFastPolicy>(s, "iisph_dijpjl", true);

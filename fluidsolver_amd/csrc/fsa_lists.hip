@@ -5,7 +5,7 @@
 // The list of a particle holds, in the order of the reference's 27-cell walk (z, y, x cell loops, ascending
 // index inside a cell; solver/sph_kernel_impl.cuh:255-260), every particle of any type whose fused squared
 // distance is below the support radius squared times 1.000002, itself included, as 16-bit entries relative to
-// the row table of its block.  Layout and limits: fsa_tile.h.
+// the row table of its block (row << 9 | index in the row; row << 10 | index for a block with large tiles).  Layout and limits: fsa_tile.h.
 #include <type_traits>
 
 #include "fsa_pair.h"
@@ -25,13 +25,16 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
     __shared__ Shared sh;
     __shared__ unsigned short queue[Q * BS];
     const int tid = threadIdx.x;
-    const int b0 = xcd_block(xcd_log) * BS;
+    const int blk = tile_block<ROWCAP>(P, xcd_log);
+    if (blk < 0) return;
+    const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     const bool active = index < n;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, 0u, 0u, P.rows);
-    if (!staged) {  // the passes walk the cells for this block
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, 0u, 0u, P.rows);
+    if (cls != 0 && cls != row_class<ROWCAP>()) return;  // the other instantiation's block
+    if (cls == 0) {  // the passes walk the cells for this block
         if (active) counts[index] = (unsigned short)kListOverflow;
         return;
     }
@@ -51,19 +54,19 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
         cnt = 0;
     };
 
-    float4 e0, e1;
+    float4 e[row_regs<BS, ROWCAP>()];
     int lj, le, nlj = 0, nle = 0;
-    row_fetch<BS, ROWCAP, false>(sh, 0, posType, e0, e1);
+    row_fetch<BS, ROWCAP, false>(sh, 0, posType, e);
     lane_range(P, sh, walk, active, 0, cellStart, lj, le);
-    row_store<BS, ROWCAP, false>(sh, 0, e0, e1);
+    row_store<BS, ROWCAP, false>(sh, 0, e);
     __syncthreads();
     for (int r = 0; r < 9; r++) {
         const int buf = r & 1;
         if (r + 1 < 9) {  // in flight during the cull below
-            row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e0, e1);
+            row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e);
             lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
         }
-        const int tag = r << 9;
+        const int tag = r << idx_bits<ROWCAP>();
         // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
         auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
             if (wave_any(cnt > Q - kChunk)) flush();
         }
         if (r + 1 < 9) {
-            row_store<BS, ROWCAP, false>(sh, buf ^ 1, e0, e1);
+            row_store<BS, ROWCAP, false>(sh, buf ^ 1, e);
             lj = nlj;
             le = nle;
             __syncthreads();
@@ -131,6 +134,10 @@ int ensure_lists(Solver *s) {
     hipLaunchKernelGGL((list_build_kernel<kTunedBS, kRowCap, kQueueL, kListSlots>), dim3(nb), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->n, (const float4 *)s->b.posType[s->cur], s->b.cellStart, s->b.sortedHash,
                        s->b.nbList, s->b.nbCount, xcd_run_log());
+    if (s->pf.big)  // blocks with rows beyond kRowCap: large tiles, entries with 10 index bits
+        hipLaunchKernelGGL((list_build_kernel<kTunedBS, kRowCapBig, kQueueL, kListSlots>), dim3((s->n + kTunedBS - 1) / kTunedBS),
+                           dim3(kTunedBS), 0, s->stream, s->pf, s->n, (const float4 *)s->b.posType[s->cur],
+                           s->b.cellStart, s->b.sortedHash, s->b.nbList, s->b.nbCount, xcd_run_log());
     FSA_HIP(hipGetLastError());
     s->lists_valid = true;
     return FSA_OK;

@@ -46,6 +46,19 @@ template <typename T> struct PassArrays {
     Vec3<T> *pressureForce;
 };
 
+// A policy may carry the neighbour's position inside its Nb record (`static constexpr bool kPosInNb = true`,
+// `Nb::pos()` returning {x, y, z, type bits}): the tiled and the list kernel then skip their own gather of
+// posType[j] -- one gather per neighbour instead of two.
+template <typename Policy, typename = void> struct pos_in_nb : std::false_type {};
+template <typename Policy> struct pos_in_nb<Policy, std::void_t<decltype(Policy::kPosInNb)>>
+    : std::bool_constant<Policy::kPosInNb> {};
+
+// `static constexpr bool kDeepReplay = true` makes the list kernel keep two batches of gathers in flight
+// instead of one: pays for policies that are light on registers.
+template <typename Policy, typename = void> struct deep_replay : std::false_type {};
+template <typename Policy> struct deep_replay<Policy, std::void_t<decltype(Policy::kDeepReplay)>>
+    : std::bool_constant<Policy::kDeepReplay> {};
+
 // One particle against its 27 cells in the reference's order, neighbours from global memory.
 template <typename T, typename Policy>
 __device__ __forceinline__ void generic_walk(const DevParams<T> &P, const PassArrays<T> &A, int index,
@@ -95,7 +108,9 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
     __shared__ Shared sh;
     __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
     const int tid = threadIdx.x;
-    const int b0 = xcd_block(xcd_log) * BS;
+    const int blk = tile_block<ROWCAP>(P, xcd_log);
+    if (blk < 0) return;
+    const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
@@ -104,6 +119,9 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
         hlo = (unsigned)sortedHash[b0];
         hhi = (unsigned)sortedHash[b0 + nb - 1];
     }
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    if (cls != 0 && cls != row_class<ROWCAP>()) return;  // the other instantiation's block
+    const bool staged = cls != 0;
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     bool active = false;
@@ -113,7 +131,6 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
         if (!active) Policy::skip(A, P, index);
     }
     if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
     typename Policy::Self S;
     if (active) Policy::init(A, P, index, S);
     if (!staged) {
@@ -138,12 +155,13 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
 #pragma unroll
         for (int u = 0; u < kDrainBatch; u++) {
             const int e = q[(s + u) * BS];
-            B.j[u] = s + u < cnt ? sh.rowStartG[e >> 9] + (e & 511) : safe;
+            B.j[u] = s + u < cnt ? sh.rowStartG[e >> idx_bits<ROWCAP>()] + (e & ((1 << idx_bits<ROWCAP>()) - 1)) : safe;
         }
 #pragma unroll
         for (int u = 0; u < kDrainBatch; u++) {
-            B.pj[u] = A.posType[B.j[u]];
             B.nb[u] = Policy::load(A, B.j[u]);
+            if constexpr (pos_in_nb<Policy>::value) B.pj[u] = B.nb[u].pos();
+            else B.pj[u] = A.posType[B.j[u]];
         }
     };
     auto batch_eval = [&](const Batch &B, int s) {
@@ -168,19 +186,19 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
         cnt = 0;
     };
 
-    float4 e0, e1;
+    float4 e[row_regs<BS, ROWCAP>()];
     int lj, le, nlj = 0, nle = 0;
-    row_fetch<BS, ROWCAP, false>(sh, 0, A.posType, e0, e1);
+    row_fetch<BS, ROWCAP, false>(sh, 0, A.posType, e);
     lane_range(P, sh, walk, active, 0, cellStart, lj, le);
-    row_store<BS, ROWCAP, true>(sh, 0, e0, e1);
+    row_store<BS, ROWCAP, true>(sh, 0, e);
     __syncthreads();
     for (int r = 0; r < 9; r++) {
         const int buf = r & 1;
         if (r + 1 < 9) {
-            row_fetch<BS, ROWCAP, false>(sh, r + 1, A.posType, e0, e1);
+            row_fetch<BS, ROWCAP, false>(sh, r + 1, A.posType, e);
             lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
         }
-        const int tag = r << 9;
+        const int tag = r << idx_bits<ROWCAP>();
         auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
             float d2[kChunk];
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
             if (wave_any(cnt > Q - kChunk)) drain();
         }
         if (r + 1 < 9) {
-            row_store<BS, ROWCAP, true>(sh, buf ^ 1, e0, e1);
+            row_store<BS, ROWCAP, true>(sh, buf ^ 1, e);
             lj = nlj;
             le = nle;
             __syncthreads();
@@ -271,37 +289,68 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
         }
         return;
     }
+    const int bits = stagedFlag == 2 ? idx_bits<kRowCapBig>() : idx_bits<kRowCap>();  // as recorded for the block's class
+    const unsigned mask = (1u << bits) - 1u;
     int cnt = active ? (int)counts[index] : 0;
     const bool overflow = cnt == kListOverflow;
     if (overflow) cnt = 0;
     const int safe = index < n ? index : 0;
     // four consecutive slots of a lane are one 8-byte word; a wavefront reads 512 contiguous bytes per word
     const uint2 *const L = reinterpret_cast<const uint2 *>(list) + (size_t)(b0 / BS) * (K / 4) * BS + tid;
-    uint2 cur = cnt > 0 ? L[0] : make_uint2(0u, 0u);
-    for (int s = 0; wave_any(s < cnt); s += 4) {
-        const uint2 nxt = s + 4 < cnt ? L[(size_t)(s / 4 + 1) * BS] : make_uint2(0u, 0u);
-        const unsigned e[4] = {cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16};
+    struct Batch {
         int j[4];
         float4 pj[4];
         typename Policy::Nb nbr[4];
+    };
+    auto entries = [&](int s) { return s < cnt ? L[(size_t)(s / 4) * BS] : make_uint2(0u, 0u); };
+    auto gather = [&](Batch &B, const uint2 w, int s) {
+        const unsigned e[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
-        for (int u = 0; u < 4; u++) j[u] = s + u < cnt ? rowStartG[e[u] >> 9] + (int)(e[u] & 511u) : safe;
+        for (int u = 0; u < 4; u++) B.j[u] = s + u < cnt ? rowStartG[e[u] >> bits] + (int)(e[u] & mask) : safe;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            pj[u] = A.posType[j[u]];
-            nbr[u] = Policy::load(A, j[u]);
+            B.nbr[u] = Policy::load(A, B.j[u]);
+            if constexpr (pos_in_nb<Policy>::value) B.pj[u] = B.nbr[u].pos();
+            else B.pj[u] = A.posType[B.j[u]];
         }
+    };
+    auto evaluate = [&](const Batch &B, int s) {
 #pragma unroll
         for (int u = 0; u < 4; u++)
             if (s + u < cnt) {
-                const int tj = unpack_int(pj[u].w);
+                const int tj = unpack_int(B.pj[u].w);
                 if (Policy::reach(tj) != 0) {
-                    const float xx = pi.x - pj[u].x, xy = pi.y - pj[u].y, xz = pi.z - pj[u].z;
+                    const float xx = pi.x - B.pj[u].x, xy = pi.y - B.pj[u].y, xz = pi.z - B.pj[u].z;
                     const float d2 = xx * xx + xy * xy + xz * xz;
-                    Policy::pair(A, P, S, j[u] == index, tj, j[u], xx, xy, xz, d2, pj[u], nbr[u]);
+                    Policy::pair(A, P, S, B.j[u] == index, tj, B.j[u], xx, xy, xz, d2, B.pj[u], B.nbr[u]);
                 }
             }
-        cur = nxt;
+    };
+    if constexpr (deep_replay<Policy>::value) {
+        // two batches of four in flight: the gathers of one are issued before the other is evaluated, and the
+        // entry words run two batches ahead
+        Batch B0, B1;
+        uint2 w1 = entries(4), w2 = entries(8);
+        gather(B0, entries(0), 0);
+        for (int s = 0; wave_any(s < cnt); s += 8) {
+            gather(B1, w1, s + 4);
+            w1 = entries(s + 12);
+            evaluate(B0, s);
+            if (!wave_any(s + 4 < cnt)) break;
+            gather(B0, w2, s + 8);
+            w2 = entries(s + 16);
+            evaluate(B1, s + 4);
+        }
+    } else {
+        // one batch of four, the next entry word in flight
+        Batch B;
+        uint2 cur = entries(0);
+        for (int s = 0; wave_any(s < cnt); s += 4) {
+            const uint2 nxt = entries(s + 4);
+            gather(B, cur, s);
+            evaluate(B, s);
+            cur = nxt;
+        }
     }
     if (overflow) generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
     if (active) Policy::finish(A, P, index, S);
@@ -366,8 +415,14 @@ template <typename Policy> static int run_tiled(Solver *s, const PassArrays<floa
         hipLaunchKernelGGL((list_pass_kernel<Policy, kTunedBS, kListSlots>), dim3(nb), dim3(kTunedBS), 0, s->stream,
                            s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, xcd_run_log());
     else
+    {
         hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, xcd_run_log());
+        if (s->pf.big)  // blocks with rows beyond kRowCap: large tiles, launched over the list of such blocks
+            hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCapBig, kQueueDf>),
+                               dim3((s->n + kTunedBS - 1) / kTunedBS), dim3(kTunedBS), 0, s->stream, s->pf, s->n, A,
+                               s->b.cellStart, s->b.sortedHash, xcd_run_log());
+    }
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

@@ -57,6 +57,7 @@ struct Buffers {
     int *gridCellStart = nullptr;  // reference format (0xffffffff for an empty cell)
     int *gridCellEnd = nullptr;
     int *blockRows = nullptr;    // row table of the tiled passes, rebuilt by every reorder (fp32)
+    int *bigBlocks = nullptr;    // count, then ids of the blocks that need the large tiles
     unsigned short *nbList = nullptr;   // recorded neighbour lists (allocated on first use), see fsa_tile.h
     unsigned short *nbCount = nullptr;  // entries per particle
     int *scanTmp = nullptr;

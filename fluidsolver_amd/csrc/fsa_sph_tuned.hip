@@ -160,7 +160,9 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
         hhi = (unsigned)sortedHash[b0 + nb - 1];
         if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
     }
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    // (blocks whose rows need the large tiles of the policy passes walk the cells here: measured, a second launch
+    // for them costs these two passes more than the walk does)
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows) == 1;
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -200,16 +202,16 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
             cnt = 0;
         };
 
-        float4 e0, e1;
+        float4 e[row_regs<BS, ROWCAP>()];
         int lj, le, nlj = 0, nle = 0;
-        row_fetch<BS, ROWCAP, true>(sh, 0, posType, e0, e1);
+        row_fetch<BS, ROWCAP, true>(sh, 0, posType, e);
         lane_range(P, sh, walk, active, 0, cellStart, lj, le);
-        row_store<BS, ROWCAP, false>(sh, 0, e0, e1);
+        row_store<BS, ROWCAP, false>(sh, 0, e);
         __syncthreads();
         for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
             const int buf = r & 1;
             if (r + 1 < 9) {  // in flight during the cull below
-                row_fetch<BS, ROWCAP, true>(sh, r + 1, posType, e0, e1);
+                row_fetch<BS, ROWCAP, true>(sh, r + 1, posType, e);
                 lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
             }
             if (ablate & 4) lj = le;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
             if (r + 1 < 9) {
-                row_store<BS, ROWCAP, false>(sh, buf ^ 1, e0, e1);
+                row_store<BS, ROWCAP, false>(sh, buf ^ 1, e);
                 lj = nlj;
                 le = nle;
                 __syncthreads();  // row r + 1 visible; everyone is done with row r - 1's buffer
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     // a block without fluid particles (wall layers) has nothing to do
     if (!__syncthreads_or(active ? 1 : 0)) return;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows) == 1;
     if (active) {
         S.v = velMass[index];
         S.pterm = pd[index].x;
@@ -411,16 +413,16 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
             cnt = 0;
         };
 
-        float4 e0, e1;
+        float4 e[row_regs<BS, ROWCAP>()];
         int lj, le, nlj = 0, nle = 0;
-        row_fetch<BS, ROWCAP, false>(sh, 0, posType, e0, e1);
+        row_fetch<BS, ROWCAP, false>(sh, 0, posType, e);
         lane_range(P, sh, walk, active, 0, cellStart, lj, le);
-        row_store<BS, ROWCAP, true>(sh, 0, e0, e1);
+        row_store<BS, ROWCAP, true>(sh, 0, e);
         __syncthreads();
         for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
             const int buf = r & 1;
             if (r + 1 < 9) {
-                row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e0, e1);
+                row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e);
                 lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
             }
             const int tag = r << 9;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
             if (r + 1 < 9) {
-                row_store<BS, ROWCAP, true>(sh, buf ^ 1, e0, e1);
+                row_store<BS, ROWCAP, true>(sh, buf ^ 1, e);
                 lj = nlj;
                 le = nle;
                 __syncthreads();

@@ -11,9 +11,16 @@ namespace fsa {
 
 constexpr int kTunedBS = 256;
 constexpr int kRowCap = 384;  // typical row: 34 cells x 8 particles = 272
+// A lattice that lines up with the cell faces puts three particle layers into some cells and one into their
+// neighbours: rows of up to 34 x 2 x 9 = 612 particles.  Blocks with such rows run in a second instantiation
+// of the tiled kernels with larger tiles (fewer blocks per CU, but there are few of them).
+constexpr int kRowCapBig = 640;
+template <int ROWCAP> constexpr int idx_bits() { return ROWCAP <= 512 ? 9 : 10; }  // entry = row << bits | index
+template <int ROWCAP> constexpr int row_class() { return ROWCAP <= kRowCap ? 1 : 2; }
 constexpr int kChunk = 4;  // candidates fetched per lane and loop trip
 constexpr int kDrainBatch = 2;  // force drain: neighbours per batch (two batches in flight)
 constexpr float kFar = 3.0e18f;
+template <int BS, int ROWCAP> constexpr int row_regs() { return (ROWCAP + kChunk + BS - 1) / BS; }  // tile entries per thread
 
 // Row tile in LDS, coordinates apart so that one 16-byte read yields four candidates.  The group
 // after the last full one (index ROWCAP / 4) only ever holds far-away padding: lanes that have nothing
@@ -30,7 +37,9 @@ template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
 
 // The row table of every block of kTunedBS consecutive sorted particles, computed once per sort and read by
 // every tiled pass until the next one: kRowTableStride ints per block = first particle of each of the 9 rows,
-// their lengths, and whether the block can be staged (every row in the grid and at most kRowCap long).
+// their lengths, and the block's class: 1 = every row in the grid and at most kRowCap long, 2 = at most
+// kRowCapBig long, 0 = neither (the block walks the cells particle by particle).  The ids of the class-2
+// blocks are also kept as a list (DevParams::big: count, then ids) for the launch that handles them.
 constexpr int kRowTableStride = 20;
 
 // Recorded neighbour lists: at most kListSlots entries per particle, 16 bits each (row << 9 | index in the row,
@@ -56,17 +65,16 @@ __device__ __forceinline__ void block_row(const DevParams<float> &P, unsigned hl
     }
 }
 
-// Block-uniform set-up.  Returns false when this block must take the per-particle path.  With a row table
-// (`rows` != nullptr) the block copies its entry; otherwise it derives the rows itself from the cells of its
-// first and last particle (hlo, hhi).
+// Block-uniform set-up.  Returns the block's class (see above).  With a row table (`rows` != nullptr) the
+// block copies its entry; otherwise it derives the rows itself from the cells of its first and last particle
+// (hlo, hhi) and knows the classes 0 and 1 only.
 template <int ROWCAP, typename Shared>
-__device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, int nb,
-                                           const int *__restrict__ cellStart,
-                                           const int *__restrict__ sortedHash, Shared &sh, unsigned hlo,
-                                           unsigned hhi, const int *__restrict__ rows = nullptr) {
+__device__ __forceinline__ int setup_rows(const DevParams<float> &P, int b0, int nb,
+                                          const int *__restrict__ cellStart,
+                                          const int *__restrict__ sortedHash, Shared &sh, unsigned hlo,
+                                          unsigned hhi, const int *__restrict__ rows = nullptr) {
     const int tid = threadIdx.x;
     if (rows) {
-        static_assert(ROWCAP == kRowCap, "the row table is built for kRowCap");
         if (tid < 19) {
             const int v = rows[(size_t)(b0 / kTunedBS) * kRowTableStride + tid];
             if (tid < 9) sh.rowStartG[tid] = v;
@@ -74,7 +82,7 @@ __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, in
             else sh.staged = v;
         }
         __syncthreads();
-        return sh.staged != 0;
+        return sh.staged;
     }
     const int C = P.num_cells;
     const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
@@ -96,47 +104,60 @@ __device__ __forceinline__ bool setup_rows(const DevParams<float> &P, int b0, in
     if (tid == 0) {
         bool ok = grid_ok;
         for (int r = 0; r < 9; r++)
-            if (sh.rowLen[r] < 0 || sh.rowLen[r] > ROWCAP) ok = false;
+            if (sh.rowLen[r] < 0 || sh.rowLen[r] > kRowCap) ok = false;
         sh.staged = ok ? 1 : 0;
     }
     __syncthreads();
-    return sh.staged != 0;
+    return sh.staged;
+}
+
+// Which block of kTunedBS particles this workgroup works on, or -1 for none: the regular instantiation maps the
+// grid onto all blocks (XCD-aware, below) and leaves class-2 blocks alone; the large-tile instantiation is
+// launched over the list of class-2 blocks.
+__device__ __forceinline__ int xcd_block(int run_log);
+template <int ROWCAP> __device__ __forceinline__ int tile_block(const DevParams<float> &P, int run_log) {
+    if constexpr (ROWCAP <= kRowCap) {
+        return xcd_block(run_log);
+    } else {
+        return (int)blockIdx.x < P.big[0] ? P.big[1 + blockIdx.x] : -1;
+    }
 }
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
-// Row r of the tile: every thread fetches its (at most two) entries into registers ...
+// Row r of the tile: every thread fetches its entries (two, or three for the large tiles) into registers ...
 // FLUID_ONLY: particles of any other type are moved far away, so that the cull needs no type test.
 template <int BS, int ROWCAP, bool FLUID_ONLY, typename Shared>
-__device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 *__restrict__ posType, float4 &e0,
-                                          float4 &e1) {
-    static_assert(ROWCAP + kChunk <= 2 * BS, "two entries per thread must cover a row");
+__device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 *__restrict__ posType,
+                                          float4 (&e)[row_regs<BS, ROWCAP>()]) {
     const int tid = threadIdx.x;
     const int s = sh.rowStartG[r], len = sh.rowLen[r];
     // entries past the row's end read some valid address and are then replaced by far-away padding
     const int last = len > 0 ? len - 1 : 0;
-    e0 = posType[s + min(tid, last)];
-    e1 = posType[s + min(tid + BS, last)];
     const float4 far = make_float4(kFar, kFar, kFar, 0.0f);
-    if (tid >= len || (FLUID_ONLY && unpack_int(e0.w) != FSA_TYPE_FLUID)) e0 = far;
-    if (tid + BS >= len || (FLUID_ONLY && unpack_int(e1.w) != FSA_TYPE_FLUID)) e1 = far;
+#pragma unroll
+    for (int k = 0; k < row_regs<BS, ROWCAP>(); k++) {
+        const int i = tid + k * BS;
+        e[k] = posType[s + min(i, last)];
+        if (i >= len || (FLUID_ONLY && unpack_int(e[k].w) != FSA_TYPE_FLUID)) e[k] = far;
+    }
 }
 // ... and stores them later, after the previous row has been examined.
 template <int BS, int ROWCAP, bool WITH_TYPE, typename Shared>
-__device__ __forceinline__ void row_store(Shared &sh, int buf, const float4 &e0, const float4 &e1) {
+__device__ __forceinline__ void row_store(Shared &sh, int buf, const float4 (&e)[row_regs<BS, ROWCAP>()]) {
     const int tid = threadIdx.x;
     float *const x = reinterpret_cast<float *>(sh.x[buf]);
     float *const y = reinterpret_cast<float *>(sh.y[buf]);
     float *const z = reinterpret_cast<float *>(sh.z[buf]);
-    x[tid] = e0.x;
-    y[tid] = e0.y;
-    z[tid] = e0.z;
-    if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[tid] = unpack_int(e0.w);
-    if (tid + BS < ROWCAP + kChunk) {
-        x[tid + BS] = e1.x;
-        y[tid + BS] = e1.y;
-        z[tid + BS] = e1.z;
-        if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[tid + BS] = unpack_int(e1.w);
+#pragma unroll
+    for (int k = 0; k < row_regs<BS, ROWCAP>(); k++) {
+        const int i = tid + k * BS;
+        if (i < ROWCAP + kChunk) {
+            x[i] = e[k].x;
+            y[i] = e[k].y;
+            z[i] = e[k].z;
+            if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[i] = unpack_int(e[k].w);
+        }
     }
 }
 

@@ -175,7 +175,9 @@ int fsa_readback_pos_color(fsa_solver *s, void *pos3, void *color4, int *n);
  * gridCellEnd (num_cells ints; gridCellEnd is only meaningful where
  * gridCellStart != 0xffffffff, as in the reference); cellStartDense
  * (num_cells + 1 ints, exclusive prefix of the per-cell counts); orderKey (n 64-bit ints, slab
- * solvers only); DF_factor pstiff error (n reals, DFSPH); the IISPH buffers listed further down.
+ * solvers only); DF_factor pstiff error (n reals, DFSPH); the IISPH buffers listed further down;
+ * neighbourCount (n ints, get only: entries of each particle's recorded neighbour list, -1 for a particle
+ * that walks the cells instead; records the lists if they are stale).
  * `bytes` must be the exact size.  Both synchronise.
  */
 int fsa_get_buffer(fsa_solver *s, const char *name, void *dst, size_t bytes);

@@ -47,14 +47,26 @@ def test_iisph_with_lists_equals_iisph_with_search(variant, crowded):
         assert a[k].tobytes() == b[k].tobytes(), k
 
 
-def test_crowded_scene_does_overflow_a_list():
-    """the scene above really has particles with more than 64 neighbours in the support"""
-    sc = iisph_scene(True)
-    pos = np.asarray(sc["pos"], np.float64)
-    fl = np.where(np.asarray(sc["type"]) == 0)[0][:400]
-    sr = float(sc["params"]["spacing"]) * float(sc["params"]["smoothratio"])
-    d = np.linalg.norm(pos[fl][:, None, :] - pos[None, fl, :], axis=2)
-    assert ((d < sr).sum(1) > 64).any()
+@pytest.mark.parametrize("crowded", [False, True], ids=["plain", "crowded"])
+def test_recorded_counts_are_the_neighbour_counts(crowded):
+    """the length of every list = the number of particles within the support (brute force), and the crowded
+    scene really has lists that overflow"""
+    sc = iisph_scene(crowded)
+    p, s = gpu_solver(sc)
+    s.setup_iisph()
+    cnt = s.get("neighbourCount")
+    pos = s.get("pos").astype(np.float64)
+    sr = float(np.float32(sc["params"]["spacing"]) * np.float32(sc["params"]["smoothratio"]))
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pos)
+    inner = np.array([len(v) for v in tree.query_ball_point(pos, sr * (1 - 1e-5))])
+    outer = np.array([len(v) for v in tree.query_ball_point(pos, sr * (1 + 1e-5))])
+    listed = cnt >= 0
+    assert np.all((cnt[listed] >= inner[listed]) & (cnt[listed] <= outer[listed]))
+    # a particle is unlisted (-1: it walks the cells) when its list would overflow or its block cannot be staged
+    assert not listed[inner > 64].any()
+    assert (inner > 64).any() == crowded
+    s.close()
 
 
 @pytest.mark.parametrize("variant", [1, 2])
@@ -95,3 +107,51 @@ def test_lists_are_rebuilt_after_positions_change_without_a_sort():
         s.close()
     for k in outs[0]:
         assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+def block_classes(s, sc):
+    """class of every block of 256 sorted particles as the row table defines it, from the sorted hashes and the
+    dense cell table: 1 = all nine rows at most 384 long, 2 = at most 640, 0 = longer or out of the grid"""
+    hs = s.get("particleHash").astype(np.int64)
+    start = s.get("cellStartDense").astype(np.int64)
+    C = len(start) - 1
+    gx, gz = int(s.params.gridres[0]), int(s.params.gridres[2])
+    out = []
+    for b0 in range(0, len(hs), 256):
+        lo, hi = hs[b0], hs[min(b0 + 256, len(hs)) - 1]
+        if hi == capi.GRID_UNDEF:
+            out.append(0)
+            continue
+        longest = 0
+        for r in range(9):
+            off = (r % 3 - 1) * gx * gz + (r // 3 - 1) * gx
+            a, e = np.clip(lo + off - 1, 0, C), np.clip(hi + off + 2, 0, C)
+            longest = max(longest, int(start[e] - start[a]))
+        out.append(1 if longest <= 384 else 2 if longest <= 640 else 0)
+    return np.array(out)
+
+
+def test_a_lattice_lined_up_with_the_cells_runs_in_large_tiles():
+    """an undisturbed lattice has cells with 12, 18 and 27 particles: rows beyond 384 entries.  Those blocks take the
+    large tiles (not the cell walk), are listed, and give the bits of the cell walk (variant 0 = variant 1)."""
+    sc = scenes.dam_break(32, 24, 32)
+    p, s = gpu_solver(sc)
+    s.set_variant(1)
+    s.sort_particles()
+    cls = block_classes(s, sc)
+    fluid = s.get("type") == 0
+    all_fluid = np.array([fluid[b0:b0 + 256].all() for b0 in range(0, len(fluid), 256)])
+    # (a run of wall particles, four to a cell, spans twice as many cells: its rows can exceed any tile)
+    assert (cls == 2).sum() > 10 and (cls[all_fluid] == 0).sum() == 0
+    cnt = s.get("neighbourCount")
+    assert (cnt[fluid] >= 0).mean() > 0.98
+    assert np.array_equal(np.repeat(cls, 256)[:len(cnt)] == 0, cnt < 0)
+    s.compute_pressure()
+    s.compute_force()
+    tiled = {k: s.get(k) for k in ("density", "pressure", "force")}
+    s.set_variant(0)
+    s.compute_pressure()
+    s.compute_force()
+    for k, v in tiled.items():
+        assert s.get(k).tobytes() == v.tobytes(), k
+    s.close()
