@@ -145,6 +145,7 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
                                                            float2 *__restrict__ pd, int ablate) {
     using Shared = RowShared<BS, ROWCAP, false>;
     __shared__ Shared sh;
+    __shared__ Segments sg;
     __shared__ float queue[Q * BS];
     const int tid = threadIdx.x;
     const int b0 = xcd_block(ablate >> 8) * BS;
@@ -160,9 +161,10 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
         hhi = (unsigned)sortedHash[b0 + nb - 1];
         if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
     }
-    // (blocks whose rows need the large tiles of the policy passes walk the cells here: measured, a second launch
-    // for them costs these two passes more than the walk does)
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows) == 1;
+    // class 2 (rows beyond a tile, up to kRowCapBig): the long rows are walked as two tiles each
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    const bool staged = cls != 0 && !(ablate & 128);
+    if (staged) setup_segments<ROWCAP>(sh, cls, sg);
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -202,17 +204,26 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
             cnt = 0;
         };
 
+        // the lane's index range inside a segment: its range in the row, cut to the segment
+        auto seg_range = [&](int row, int off, int len, int &a, int &b) {
+            lane_range(P, sh, walk, active, row, cellStart, a, b);
+            a = min(max(a - off, 0), len);
+            b = min(max(b - off, 0), len);
+        };
         float4 e[row_regs<BS, ROWCAP>()];
         int lj, le, nlj = 0, nle = 0;
-        row_fetch<BS, ROWCAP, true>(sh, 0, posType, e);
-        lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+        const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
+        tile_fetch<BS, ROWCAP, true>(sh.rowStartG[0], len0, posType, e);
+        seg_range(0, 0, len0, lj, le);
         row_store<BS, ROWCAP, false>(sh, 0, e);
         __syncthreads();
-        for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
+        const int nseg = (ablate & 8) ? 0 : sg.count;
+        for (int r = 0; r < nseg; r++) {
             const int buf = r & 1;
-            if (r + 1 < 9) {  // in flight during the cull below
-                row_fetch<BS, ROWCAP, true>(sh, r + 1, posType, e);
-                lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+            if (r + 1 < nseg) {  // in flight during the cull below
+                const int row = sg.row[r + 1], st = sg.start[r + 1], len = sg.len[r + 1];
+                tile_fetch<BS, ROWCAP, true>(st, len, posType, e);
+                seg_range(row, st - sh.rowStartG[row], len, nlj, nle);
             }
             if (ablate & 4) lj = le;
             // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
@@ -245,11 +256,11 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
                 cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
-            if (r + 1 < 9) {
+            if (r + 1 < nseg) {
                 row_store<BS, ROWCAP, false>(sh, buf ^ 1, e);
                 lj = nlj;
                 le = nle;
-                __syncthreads();  // row r + 1 visible; everyone is done with row r - 1's buffer
+                __syncthreads();  // segment r + 1 visible; everyone is done with the buffer of segment r - 1
             }
         }
         drain();
@@ -295,6 +306,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                                                          Vec3<float> *__restrict__ force, int ablate) {
     using Shared = RowShared<BS, ROWCAP, true>;
     __shared__ Shared sh;
+    __shared__ Segments sg;
     __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
     const int tid = threadIdx.x;
     const int b0 = xcd_block(ablate >> 8) * BS;
@@ -322,7 +334,9 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
     }
     // a block without fluid particles (wall layers) has nothing to do
     if (!__syncthreads_or(active ? 1 : 0)) return;
-    const bool staged = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows) == 1;
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    const bool staged = cls != 0 && !(ablate & 128);
+    if (staged) setup_segments<ROWCAP>(sh, cls, sg);  // long rows as two tiles each, see the density kernel
     if (active) {
         S.v = velMass[index];
         S.pterm = pd[index].x;
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
 #pragma unroll
             for (int u = 0; u < kDrainBatch; u++) {
                 const int e = q[(s + u) * BS];
-                B.j[u] = (s + u < cnt && !(ablate & 64)) ? sh.rowStartG[e >> 9] + (e & 511) : safe;
+                B.j[u] = (s + u < cnt && !(ablate & 64)) ? sg.start[e >> 9] + (e & 511) : safe;
             }
 #pragma unroll
             for (int u = 0; u < kDrainBatch; u++) {
@@ -413,19 +427,27 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
             cnt = 0;
         };
 
+        auto seg_range = [&](int row, int off, int len, int &a, int &b) {
+            lane_range(P, sh, walk, active, row, cellStart, a, b);
+            a = min(max(a - off, 0), len);
+            b = min(max(b - off, 0), len);
+        };
         float4 e[row_regs<BS, ROWCAP>()];
         int lj, le, nlj = 0, nle = 0;
-        row_fetch<BS, ROWCAP, false>(sh, 0, posType, e);
-        lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+        const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
+        tile_fetch<BS, ROWCAP, false>(sh.rowStartG[0], len0, posType, e);
+        seg_range(0, 0, len0, lj, le);
         row_store<BS, ROWCAP, true>(sh, 0, e);
         __syncthreads();
-        for (int r = 0; r < ((ablate & 8) ? 0 : 9); r++) {
+        const int nseg = (ablate & 8) ? 0 : sg.count;
+        for (int r = 0; r < nseg; r++) {
             const int buf = r & 1;
-            if (r + 1 < 9) {
-                row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e);
-                lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+            if (r + 1 < nseg) {
+                const int row = sg.row[r + 1], st = sg.start[r + 1], len = sg.len[r + 1];
+                tile_fetch<BS, ROWCAP, false>(st, len, posType, e);
+                seg_range(row, st - sh.rowStartG[row], len, nlj, nle);
             }
-            const int tag = r << 9;
+            const int tag = r << 9;  // queue entries: segment << 9 | index in the segment
             if (ablate & 4) lj = le;
             // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
             auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                 cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
                 if (wave_any(cnt > Q - kChunk)) drain();
             }
-            if (r + 1 < 9) {
+            if (r + 1 < nseg) {
                 row_store<BS, ROWCAP, true>(sh, buf ^ 1, e);
                 lj = nlj;
                 le = nle;

@@ -125,14 +125,14 @@ template <int ROWCAP> __device__ __forceinline__ int tile_block(const DevParams<
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
-// Row r of the tile: every thread fetches its entries (two, or three for the large tiles) into registers ...
+// `len` consecutive particles from `s` on, for one tile: every thread fetches its entries (two, or three for the
+// large tiles) into registers ...
 // FLUID_ONLY: particles of any other type are moved far away, so that the cull needs no type test.
-template <int BS, int ROWCAP, bool FLUID_ONLY, typename Shared>
-__device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 *__restrict__ posType,
-                                          float4 (&e)[row_regs<BS, ROWCAP>()]) {
+template <int BS, int ROWCAP, bool FLUID_ONLY>
+__device__ __forceinline__ void tile_fetch(int s, int len, const float4 *__restrict__ posType,
+                                           float4 (&e)[row_regs<BS, ROWCAP>()]) {
     const int tid = threadIdx.x;
-    const int s = sh.rowStartG[r], len = sh.rowLen[r];
-    // entries past the row's end read some valid address and are then replaced by far-away padding
+    // entries past the end read some valid address and are then replaced by far-away padding
     const int last = len > 0 ? len - 1 : 0;
     const float4 far = make_float4(kFar, kFar, kFar, 0.0f);
 #pragma unroll
@@ -141,6 +141,12 @@ __device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 
         e[k] = posType[s + min(i, last)];
         if (i >= len || (FLUID_ONLY && unpack_int(e[k].w) != FSA_TYPE_FLUID)) e[k] = far;
     }
+}
+// Row r of the block as one tile.
+template <int BS, int ROWCAP, bool FLUID_ONLY, typename Shared>
+__device__ __forceinline__ void row_fetch(const Shared &sh, int r, const float4 *__restrict__ posType,
+                                          float4 (&e)[row_regs<BS, ROWCAP>()]) {
+    tile_fetch<BS, ROWCAP, FLUID_ONLY>(sh.rowStartG[r], sh.rowLen[r], posType, e);
 }
 // ... and stores them later, after the previous row has been examined.
 template <int BS, int ROWCAP, bool WITH_TYPE, typename Shared>
@@ -158,6 +164,43 @@ __device__ __forceinline__ void row_store(Shared &sh, int buf, const float4 (&e)
             z[i] = e[k].z;
             if (WITH_TYPE) reinterpret_cast<int *>(sh.t[buf])[i] = unpack_int(e[k].w);
         }
+    }
+}
+
+// Segments (WCSPH density and force kernels): a row longer than a tile is walked as two tiles.  A block of class 1
+// has its nine rows as nine segments; a block of class 2 (rows up to kRowCapBig, see above) up to 18.
+constexpr int kMaxSegs = 18;
+struct Segments {
+    int start[kMaxSegs];  // first particle (global index)
+    int len[kMaxSegs];
+    int row[kMaxSegs];    // which of the nine rows
+    int count;
+};
+// Fills the segment table (call after setup_rows; visible after the next barrier).
+template <int ROWCAP, typename Shared>
+__device__ __forceinline__ void setup_segments(const Shared &sh, int cls, Segments &sg) {
+    const int tid = threadIdx.x;
+    if (cls == 1) {
+        if (tid < 9) {
+            sg.start[tid] = sh.rowStartG[tid];
+            sg.len[tid] = sh.rowLen[tid];
+            sg.row[tid] = tid;
+        }
+        if (tid == 9) sg.count = 9;
+    } else if (tid == 0) {
+        int k = 0;
+        for (int r = 0; r < 9; r++) {
+            const int len = sh.rowLen[r], st = sh.rowStartG[r];
+            int o = 0;
+            do {
+                sg.start[k] = st + o;
+                sg.len[k] = min(ROWCAP, len - o);
+                sg.row[k] = r;
+                k++;
+                o += ROWCAP;
+            } while (o < len && k < kMaxSegs);
+        }
+        sg.count = k;
     }
 }
 

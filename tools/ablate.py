@@ -20,4 +20,4 @@ for which, name in ((0, "density"), (1, "force")):
         capi.check(lib.fsa_debug_time_pass(s._h, which, ab, 5))
         t = s.timing_read(); s.timing_enable(False)
         k = name + "_dbg"
-        print(f"{name} ablate={ab} (1=no drain 2=no append 4=no cull): {t[k][1]/t[k][0]:.3f} ms")
+        print(f"{name} ablate={ab} (1=no drain 2=no append 4=no cull 128=every block walks the cells): {t[k][1]/t[k][0]:.3f} ms")
