@@ -5,7 +5,8 @@
 // The list of a particle holds, in the order of the reference's 27-cell walk (z, y, x cell loops, ascending
 // index inside a cell; solver/sph_kernel_impl.cuh:255-260), every particle of any type whose fused squared
 // distance is below the support radius squared times 1.000002, itself included, as 16-bit entries relative to
-// the row table of its block (row << 9 | index in the row; row << 10 | index for a block with large tiles).  Layout and limits: fsa_tile.h.
+// the row table of its block (row << 9 | index in the row; row << 10 | index for a block with large tiles).
+// Layout and limits: fsa_tile.h.
 #include <type_traits>
 
 #include "fsa_pair.h"
@@ -116,17 +117,18 @@ int ensure_lists(Solver *s) {
         s->lists_valid = false;
         return FSA_OK;  // the passes use the tiles
     }
-    if (!s->b.nbList) {  // sized for the solver's capacity, kept until fsa_destroy
+    if (!s->b.nbList || !s->b.nbCount) {  // sized for the solver's capacity, kept until fsa_destroy
         const size_t blocks = ((size_t)s->capacity + kTunedBS - 1) / kTunedBS + 1;
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, blocks * kListSlots * kTunedBS * sizeof(unsigned short));
-        if (e != hipSuccess)
-            return fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour lists (%zu blocks) failed: %s", blocks,
-                        hipGetErrorString(e));
-        s->b.nbList = (unsigned short *)p;
-        e = hipMalloc(&p, blocks * kTunedBS * sizeof(unsigned short));
-        if (e != hipSuccess) return fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour counts failed: %s", hipGetErrorString(e));
-        s->b.nbCount = (unsigned short *)p;
+        void *lists = nullptr, *counts = nullptr;
+        hipError_t e = hipMalloc(&lists, blocks * kListSlots * kTunedBS * sizeof(unsigned short));
+        if (e == hipSuccess) e = hipMalloc(&counts, blocks * kTunedBS * sizeof(unsigned short));
+        if (e != hipSuccess) {
+            if (lists) (void)hipFree(lists);
+            return fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour lists (%zu blocks of %d particles) failed: %s", blocks,
+                        kTunedBS, hipGetErrorString(e));
+        }
+        s->b.nbList = (unsigned short *)lists;
+        s->b.nbCount = (unsigned short *)counts;
     }
     ScopedTimer t(s, "list_build");
     const int unit = kXcds << xcd_run_log();
