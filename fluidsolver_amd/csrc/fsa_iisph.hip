@@ -38,6 +38,16 @@ __device__ __forceinline__ void kernel_gradient_cubic(const DevParams<T> &P, T h
     gz = z * df * P.kernel_cubic_gradient / r;
 }
 
+// fast fp32 flavour of the same gradient, as a factor of xij
+__device__ __forceinline__ float grad_scale_fast(float d2, float inv_h, float kgrad) {
+    // gradW = xij * (df * kernel_cubic_gradient / r), KernelGradient_Cubic :42-54; 0 for q = 0 and q >= 2
+    const float rinv = __builtin_amdgcn_rsqf(d2);
+    const float q = d2 * rinv * inv_h;
+    const float two_q = 2.0f - q;
+    const float df = q >= 1.0f ? -0.5f * two_q * two_q : q * __builtin_fmaf(1.5f, q, -2.0f);
+    return (d2 > 0.0f && q < 2.0f) ? df * kgrad * rinv : 0.0f;
+}
+
 // the three `case` labels that share one body in every IISPH cell function
 __device__ __forceinline__ bool fluid_like(int t) {
     return t == FSA_TYPE_FLUID || t == FSA_TYPE_DEFORMABLE || t == FSA_TYPE_CLOTH;
@@ -163,7 +173,9 @@ template <typename T> struct NpfMultiPolicy {
 };
 
 // ---- IISPHFactorCell :3665-3715 + IISPHFactorKernel :3717-3749 ----------------------------------------
-template <typename T> struct IisphFactorPolicy {
+// FAST (fp32, variant 2): hardware square root / reciprocal square root and fused multiply-adds, no double
+// arithmetic per pair; about 1e-6 relative away from the exact flavour per term
+template <typename T, bool FAST = false> struct IisphFactorPolicy {
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
     struct Self { T dens, sx, sy, sz, mass, rd; };
     struct Nb { T rd; };
@@ -179,6 +191,16 @@ template <typename T> struct IisphFactorPolicy {
                                                 int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
+        if constexpr (FAST) {
+            const float inv_h = 2.0f / (float)sr;
+            const float mj = fluid_like(tj) ? (float)S.mass : (tj == FSA_TYPE_RIGID ? (float)(nb.rd * S.rd) : 0.0f);
+            const float gm = grad_scale_fast((float)d2, inv_h, (float)P.kernel_cubic_gradient) * mj;
+            S.sx = (T)__builtin_fmaf((float)xx, gm, (float)S.sx);
+            S.sy = (T)__builtin_fmaf((float)xy, gm, (float)S.sy);
+            S.sz = (T)__builtin_fmaf((float)xz, gm, (float)S.sz);
+            S.dens = (T)__builtin_fmaf(cubic_fast((float)d2, inv_h, (float)P.kernel_cubic), mj, (float)S.dens);
+            return;
+        }
         T gx, gy, gz;
         kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
         T mass_j;
@@ -201,7 +223,7 @@ template <typename T> struct IisphFactorPolicy {
 };
 
 // ---- IISPHPredictDensityCell :3751-3805 + IISPHPredictDensityKernel :3807-3833 ------------------------
-template <typename T> struct IisphPredictPolicy {
+template <typename T, bool FAST = false> struct IisphPredictPolicy {
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
     struct Self { T dens, aii, dens_i, mass, rd; Vec3<T> vs, dii; };
     struct Nb { T vx, vy, vz, rd; };
@@ -217,6 +239,10 @@ template <typename T> struct IisphPredictPolicy {
         S.dii = A.dii[index];
     }
     static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        if constexpr (FAST) {  // {v_star, restDensity} packed by iisph_pack_vstar_rd_kernel: one gather
+            const Vec4<T> a = A.aux4[j];
+            return Nb{a.x, a.y, a.z, a.w};
+        }
         const Vec3<T> v = A.vStarIn[j];
         return Nb{v.x, v.y, v.z, A.restDensity[j]};
     }
@@ -224,6 +250,22 @@ template <typename T> struct IisphPredictPolicy {
                                                 int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
+        if constexpr (FAST) {
+            const bool fl = fluid_like(tj);
+            if (!fl && tj != FSA_TYPE_RIGID) return;
+            const float gs = grad_scale_fast((float)d2, 2.0f / (float)sr, (float)P.kernel_cubic_gradient);
+            const float gx = (float)xx * gs, gy = (float)xy * gs, gz = (float)xz * gs;
+            const float mj = fl ? (float)S.mass : (float)(nb.rd * S.rd);
+            // a rigid neighbour does not move: its v_star counts as zero (:3790)
+            const float ux = (float)S.vs.x - (fl ? (float)nb.vx : 0.0f), uy = (float)S.vs.y - (fl ? (float)nb.vy : 0.0f),
+                        uz = (float)S.vs.z - (fl ? (float)nb.vz : 0.0f);
+            const float dv = __builtin_fmaf(ux, gx, __builtin_fmaf(uy, gy, uz * gz));
+            S.dens = (T)__builtin_fmaf((float)P.dt * mj, dv, (float)S.dens);
+            const float k = mj * (float)P.dt * (float)P.dt / ((float)S.dens_i * (float)S.dens_i);  // d_ji = gradW * k
+            const float lx = (float)S.dii.x - gx * k, ly = (float)S.dii.y - gy * k, lz = (float)S.dii.z - gz * k;
+            S.aii = (T)__builtin_fmaf(mj, __builtin_fmaf(lx, gx, __builtin_fmaf(ly, gy, lz * gz)), (float)S.aii);
+            return;
+        }
         T gx, gy, gz;
         kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
         T mass_j;
@@ -336,7 +378,7 @@ template <typename T> struct IisphNewPressurePolicy {
 };
 
 // ---- CalcPressureForceCell :3998-4046 + CalcPressureForceKernel :4048-4065 ---------------------------
-template <typename T> struct IisphPressureForcePolicy {
+template <typename T, bool FAST = false> struct IisphPressureForcePolicy {
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
     struct Self { T fx, fy, fz, p_i, dens_i, mass, rd; };
     struct Nb { T pressure, dens, rd; };
@@ -350,12 +392,29 @@ template <typename T> struct IisphPressureForcePolicy {
         S.rd = A.restDensity[index];
     }
     static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        if constexpr (FAST) {  // {p / rho^2 (0 for a rigid particle), restDensity} packed by iisph_pack_pterm_rd_kernel
+            const float2 v = reinterpret_cast<const float2 *>(A.aux2)[j];
+            return Nb{(T)v.x, (T)1, (T)v.y};
+        }
         return Nb{A.pressure[j], A.density[j], A.restDensity[j]};
     }
     static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
                                                 int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         const T sr = P.sr, sr2 = sr * sr;
         if (d2 >= sr2) return;
+        if constexpr (FAST) {
+            const bool fl = fluid_like(tj);
+            if (!fl && tj != FSA_TYPE_RIGID) return;
+            const float gs = grad_scale_fast((float)d2, 2.0f / (float)sr, (float)P.kernel_cubic_gradient);
+            const float wi = (float)S.p_i / ((float)S.dens_i * (float)S.dens_i);
+            const float wj = fl ? (float)nb.pressure : 0.0f;  // p_j / rho_j^2, packed
+            const float mj = fl ? (float)S.mass : (float)(nb.rd * S.rd);
+            const float f = -gs * (float)S.mass * mj * (wi + wj);
+            S.fx = (T)__builtin_fmaf((float)xx, f, (float)S.fx);
+            S.fy = (T)__builtin_fmaf((float)xy, f, (float)S.fy);
+            S.fz = (T)__builtin_fmaf((float)xz, f, (float)S.fz);
+            return;
+        }
         T gx, gy, gz;
         kernel_gradient_cubic(P, sr / 2, xx, xy, xz, d2, gx, gy, gz);
         if (fluid_like(tj)) {
@@ -469,15 +528,6 @@ __global__ __launch_bounds__(kBlock) void block_sum_kernel(int n, const T *__res
 //   CalcDIJPJL        reads  {x_j, p_j / rho_j^2}
 //   CalcNewPressure   reads  {d_jj p_j + dijpjl_j, restDensity_j}
 // About 1e-6 relative away from the exact flavour per term.
-__device__ __forceinline__ float grad_scale_fast(float d2, float inv_h, float kgrad) {
-    // gradW = xij * (df * kernel_cubic_gradient / r), KernelGradient_Cubic :42-54; 0 for q = 0 and q >= 2
-    const float rinv = __builtin_amdgcn_rsqf(d2);
-    const float q = d2 * rinv * inv_h;
-    const float two_q = 2.0f - q;
-    const float df = q >= 1.0f ? -0.5f * two_q * two_q : q * __builtin_fmaf(1.5f, q, -2.0f);
-    return (d2 > 0.0f && q < 2.0f) ? df * kgrad * rinv : 0.0f;
-}
-
 // {x, y, z, p / rho^2}: all CalcDIJPJL reads of a neighbour.  The last entry is 0 for a particle that does not
 // count (rigid ones, whose density is never set): its term then adds an exact zero.
 __global__ __launch_bounds__(kBlock) void iisph_pack_pterm_kernel(int n, const float4 *__restrict__ posType,
@@ -589,6 +639,26 @@ struct IisphNewPressureFastPolicy {
     }
 };
 
+// packed neighbour records of the fast predict and pressure-force passes
+__global__ __launch_bounds__(kBlock) void iisph_pack_vstar_rd_kernel(int n, const Vec3<float> *__restrict__ v_star,
+                                                                     const float *__restrict__ restDensity,
+                                                                     float4 *__restrict__ rec) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Vec3<float> v = v_star[i];
+    rec[i] = make_float4(v.x, v.y, v.z, restDensity[i]);
+}
+__global__ __launch_bounds__(kBlock) void iisph_pack_pterm_rd_kernel(int n, const float4 *__restrict__ posType,
+                                                                     const float *__restrict__ pressure,
+                                                                     const float *__restrict__ density,
+                                                                     const float *__restrict__ restDensity,
+                                                                     float2 *__restrict__ rec) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float d = density[i];
+    rec[i] = make_float2(fluid_like(unpack_int(posType[i].w)) ? pressure[i] / d / d : 0.0f, restDensity[i]);
+}
+
 static bool use_fast(const Solver *s) { return use_tiles(s) && s->variant >= 2; }
 
 #define IISPH_PASS(PolicyName, tag)                                              \
@@ -610,8 +680,23 @@ int launch_effective_mass(Solver *s) {
 }
 
 int launch_npf_multiphase(Solver *s) { IISPH_PASS(NpfMultiPolicy, "npf_multiphase"); }
-int launch_iisph_factor(Solver *s) { IISPH_PASS(IisphFactorPolicy, "iisph_factor"); }
-int launch_iisph_predict_density(Solver *s) { IISPH_PASS(IisphPredictPolicy, "iisph_predict"); }
+int launch_iisph_factor(Solver *s) {
+    if (s->n > 0 && use_fast(s)) return launch_tuned<IisphFactorPolicy<float, true>>(s, "iisph_factor", true);
+    IISPH_PASS(IisphFactorPolicy, "iisph_factor");
+}
+int launch_iisph_predict_density(Solver *s) {
+    if (s->n > 0 && use_fast(s)) {
+        {
+            ScopedTimer t(s, "iisph_pack_vstar_rd");
+            hipLaunchKernelGGL(iisph_pack_vstar_rd_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                               (const Vec3<float> *)s->b.v_star, (const float *)s->b.restDensity[s->cur],
+                               (float4 *)s->b.aux4);
+            FSA_HIP(hipGetLastError());
+        }
+        return launch_tuned<IisphPredictPolicy<float, true>>(s, "iisph_predict", true);
+    }
+    IISPH_PASS(IisphPredictPolicy, "iisph_predict");
+}
 int launch_iisph_dijpjl(Solver *s) {
     if (s->n == 0) return FSA_OK;
     if (use_fast(s)) {
@@ -626,7 +711,21 @@ int launch_iisph_dijpjl(Solver *s) {
     }
     IISPH_PASS(IisphDijpjlPolicy, "iisph_dijpjl");
 }
-int launch_iisph_pressure_force(Solver *s) { IISPH_PASS(IisphPressureForcePolicy, "iisph_pforce"); }
+int launch_iisph_pressure_force(Solver *s) {
+    if (s->n > 0 && use_fast(s)) {
+        {
+            ScopedTimer t(s, "iisph_pack_pterm_rd");
+            s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
+            hipLaunchKernelGGL(iisph_pack_pterm_rd_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                               (const float4 *)s->b.posType[s->cur], (const float *)s->b.pressure,
+                               (const float *)s->b.density, (const float *)s->b.restDensity[s->cur],
+                               (float2 *)s->b.pd);
+            FSA_HIP(hipGetLastError());
+        }
+        return launch_tuned<IisphPressureForcePolicy<float, true>>(s, "iisph_pforce", true);
+    }
+    IISPH_PASS(IisphPressureForcePolicy, "iisph_pforce");
+}
 
 int launch_iisph_new_pressure(Solver *s) {
     if (s->n == 0) return FSA_OK;

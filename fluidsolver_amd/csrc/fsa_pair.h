@@ -22,6 +22,18 @@ __device__ __forceinline__ void density_pair(const DevParams<T> &P, T h, T sr2, 
     if (tj == FSA_TYPE_RIGID) dens += rd_i * restDensity[j] * wij;
 }
 
+// Cubic spline of Kernel_Cubic (solver/sph_kernel_impl.cuh:32-40) in the fast fp32 flavour: hardware square root,
+// fused multiply-adds, both branches evaluated and one selected.
+__device__ __forceinline__ float cubic_fast(float d2, float inv_h, float kcubic) {
+    const float q = __builtin_amdgcn_sqrtf(d2) * inv_h;
+    // q < 1: (0.666667 - q^2 + 0.5 q^3) * 1.5     1 <= q < 2: 0.25 (2 - q)^3
+    const float q2 = q * q;
+    const float w1 = __builtin_fmaf(q2, __builtin_fmaf(0.75f, q, -1.5f), 1.0000005f);
+    const float t = 2.0f - q;
+    const float w2 = 0.25f * t * t * t;
+    return (q < 1.0f ? w1 : w2) * kcubic;
+}
+
 // Per-particle state of the force pass.
 template <typename T> struct ForceSelf {
     Vec4<T> p;  // position, type

@@ -40,16 +40,6 @@
 namespace fsa {
 
 // ---- fast fp32 pair arithmetic -----------------------------------------------------------------
-__device__ __forceinline__ float cubic_fast(float d2, float inv_h, float kcubic) {
-    const float q = __builtin_amdgcn_sqrtf(d2) * inv_h;
-    // q < 1: (0.666667 - q^2 + 0.5 q^3) * 1.5     1 <= q < 2: 0.25 (2 - q)^3
-    const float q2 = q * q;
-    const float w1 = __builtin_fmaf(q2, __builtin_fmaf(0.75f, q, -1.5f), 1.0000005f);
-    const float t = 2.0f - q;
-    const float w2 = 0.25f * t * t * t;
-    return (q < 1.0f ? w1 : w2) * kcubic;
-}
-
 // One fluid-fluid pair of the force pass in the fast flavour.  `ok` = the pair counts (inside the
 // support, not the particle itself, a fluid neighbour); a pair that does not count adds exact zeros.
 __device__ __forceinline__ void force_pair_fast(ForceSelf<float> &S, float sr, float kspiky, float visc_eps,

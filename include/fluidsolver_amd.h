@@ -284,9 +284,9 @@ int fsa_timing_read(fsa_solver *s, fsa_kernel_time *out, int cap, int *count);
  *      operation for operation as the reference's expressions;
  *   1  tuned structure (LDS row tiles + per-lane hit queues), same exact arithmetic;
  *   2  tuned structure, fast fp32 arithmetic (hardware sqrt/rsq/rcp, fused multiply-adds): about
- *      1e-7 relative away from variant 1 per neighbour term.  Default.  The two kernels of an IISPH
- *      relaxation round and the three of the DFSPH correction loops have such a flavour too; the remaining
- *      DFSPH and IISPH passes run the exact arithmetic in every variant. */
+ *      1e-7 relative away from variant 1 per neighbour term.  Default.  The IISPH passes (all but the
+ *      non-pressure force) and the three kernels of the DFSPH correction loops have such a flavour too; the
+ *      remaining DFSPH and IISPH passes run the exact arithmetic in every variant. */
 int fsa_set_variant(fsa_solver *s, int variant);
 
 /* Recorded neighbour lists (fp32, variants 1 and 2; no counterpart in the reference, which walks the 27
