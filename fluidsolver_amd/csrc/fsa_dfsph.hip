@@ -108,6 +108,7 @@ template <typename T> struct NpfPolicy {
 // TIMES_DT = false: solveDivergenceStiff :818-842; true: solveDensityStiff :890-919
 // FAST (fp32, variant 2): hardware reciprocal square root and fused multiply-adds, about 1e-7 relative per term
 template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct StiffPolicy {
+    static constexpr bool kDeepReplay = FAST;
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T acc; Vec3<T> vs; };
@@ -179,6 +180,7 @@ template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct Stif
 // Neighbours are read through pos / pstiff / density only, v_star is written for the particle itself:
 // no ordering hazard between threads.
 template <typename T, bool PACKED, bool FAST = false> struct ApplyPolicy {
+    static constexpr bool kDeepReplay = FAST;
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T wi, fx, fy, fz; };
