@@ -14,6 +14,7 @@ namespace fsa {
 
 // ---- DensityAlphaCell :582-624 + computeDensityAlpha_kernel :626-660 -------------------------------
 template <typename T> struct AlphaPolicy {
+    static constexpr bool kDeepReplay = true;
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T dens, mwij, mx, my, mz, mass; };

@@ -224,6 +224,7 @@ template <typename T, bool FAST = false> struct IisphFactorPolicy {
 
 // ---- IISPHPredictDensityCell :3751-3805 + IISPHPredictDensityKernel :3807-3833 ------------------------
 template <typename T, bool FAST = false> struct IisphPredictPolicy {
+    static constexpr bool kDeepReplay = FAST;
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
     struct Self { T dens, aii, dens_i, mass, rd; Vec3<T> vs, dii; };
     struct Nb { T vx, vy, vz, rd; };
@@ -379,6 +380,7 @@ template <typename T> struct IisphNewPressurePolicy {
 
 // ---- CalcPressureForceCell :3998-4046 + CalcPressureForceKernel :4048-4065 ---------------------------
 template <typename T, bool FAST = false> struct IisphPressureForcePolicy {
+    static constexpr bool kDeepReplay = FAST;
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
     struct Self { T fx, fy, fz, p_i, dens_i, mass, rd; };
     struct Nb { T pressure, dens, rd; };
