@@ -263,7 +263,7 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
                                                        const int *__restrict__ cellStart,
                                                        const unsigned short *__restrict__ list,
                                                        const unsigned short *__restrict__ counts, int xcd_log) {
-    __shared__ int rowStartG[9];
+    __shared__ int rowStartG[16];  // 9 used
     __shared__ int stagedFlag;
     const int tid = threadIdx.x;
     const int b0 = xcd_block(xcd_log) * BS;
@@ -306,7 +306,12 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
     auto gather = [&](Batch &B, const uint2 w, int s) {
         const unsigned e[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
-        for (int u = 0; u < 4; u++) B.j[u] = s + u < cnt ? rowStartG[e[u] >> bits] + (int)(e[u] & mask) : safe;
+        for (int u = 0; u < 4; u++) {
+            // (the row look-up is unconditional -- slots past the end hold entry 0 -- so that the four LDS reads are
+            // issued together and a select, not a branch, picks the lane's own index for an unused slot)
+            const int jr = rowStartG[(e[u] >> bits) & 15u] + (int)(e[u] & mask);  // (& 15: stale slots of the last word)
+            B.j[u] = s + u < cnt ? jr : safe;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             B.nbr[u] = Policy::load(A, B.j[u]);
