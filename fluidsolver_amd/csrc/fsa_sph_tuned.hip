@@ -20,7 +20,7 @@
 //     busy.  Queues are first-in first-out: each particle's sum is accumulated in the reference's
 //     neighbour order.
 //
-// LDS per workgroup is 29-37 KiB, which keeps four workgroups (16 wavefronts) on a CU: the VALU
+// LDS per workgroup is 20 KiB (density, eight workgroups per CU) and 39 KiB (force, four): the VALU
 // of gfx950 needs about four wavefronts per SIMD to issue at its full rate.
 //
 // Two arithmetic flavours share this structure:
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-constexpr int kQueueD = 12;   // density: 4-byte slots
+constexpr int kQueueD = 10;   // density: 4-byte slots (with the tile: 19.9 KB, eight blocks per CU)
 constexpr int kQueueF = 48;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
