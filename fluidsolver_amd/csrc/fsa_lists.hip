@@ -24,7 +24,7 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
                                                         unsigned short *__restrict__ counts, int xcd_log) {
     using Shared = RowShared<BS, ROWCAP, false>;
     __shared__ Shared sh;
-    __shared__ unsigned short queue[Q * BS];
+    __shared__ unsigned short queue[(Q + 4) * BS];  // the flush reads up to three slots past the last entry
     const int tid = threadIdx.x;
     const int blk = tile_block<ROWCAP>(P, xcd_log);
     if (blk < 0) return;
@@ -44,15 +44,30 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
     const float sr2c = P.sr * P.sr * 1.000002f;
     const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
     unsigned short *const q = queue + tid;
-    unsigned short *const L = list + ((size_t)(b0 / BS) * (K / 4) * BS + tid) * 4;
-    int cnt = 0, total = 0;
-    auto flush = [&]() {
-        for (int s = 0; wave_any(s < cnt); s++) {
-            const int slot = total + s;
-            if (s < cnt && slot < K) L[(size_t)(slot >> 2) * (BS * 4) + (slot & 3)] = q[s * BS];
+    uint2 *const L = reinterpret_cast<uint2 *>(list) + (size_t)(b0 / BS) * (K / 4) * BS + tid;
+    int cnt = 0, total = 0;  // entries in the queue; entries written out (a multiple of four until the last flush)
+    // Whole words (four entries, 8 bytes per lane: the 64 lanes of a wavefront store 512 contiguous bytes) go
+    // out; up to three left-over entries move to the head of the queue and wait for the next flush.
+    auto flush = [&](bool last) {
+        const int full = last ? cnt : (cnt & ~3);
+        for (int w = 0; wave_any(4 * w < full); w++) {
+            unsigned e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned v = q[(4 * w + u) * BS];
+                e4[u] = 4 * w + u < full ? v : 0u;
+            }
+            const int slot = total + 4 * w;
+            if (4 * w < full && slot < K) L[(size_t)(slot >> 2) * BS] = make_uint2(e4[0] | (e4[1] << 16), e4[2] | (e4[3] << 16));
         }
-        total += cnt;
-        cnt = 0;
+        const int rem = cnt - full;  // 0 .. 3 (0 after the last flush)
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const unsigned short v = q[(full + u) * BS];
+            if (u < rem) q[u * BS] = v;
+        }
+        total += full;
+        cnt = rem;
     };
 
     float4 e[row_regs<BS, ROWCAP>()];
@@ -84,19 +99,19 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
         int base = lj & ~(kChunk - 1);
         if (wave_any(has)) {  // first group of the range
             cull_group(has ? base / kChunk : Shared::kPad, lj - base, le - base, std::true_type());
-            if (wave_any(cnt > Q - kChunk)) flush();
+            if (wave_any(cnt > Q - kChunk)) flush(false);
         }
         base = has ? base + kChunk : le;
         while (wave_any(base + kChunk <= le)) {  // whole groups
             const bool go = base + kChunk <= le;
             cull_group(go ? base / kChunk : Shared::kPad, 0, kChunk, std::false_type());
             base += go ? kChunk : 0;
-            if (wave_any(cnt > Q - kChunk)) flush();
+            if (wave_any(cnt > Q - kChunk)) flush(false);
         }
         if (wave_any(base < le)) {  // last group of the range
             const int rem = le - base;
             cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
-            if (wave_any(cnt > Q - kChunk)) flush();
+            if (wave_any(cnt > Q - kChunk)) flush(false);
         }
         if (r + 1 < 9) {
             row_store<BS, ROWCAP, false>(sh, buf ^ 1, e);
@@ -105,7 +120,7 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
             __syncthreads();
         }
     }
-    flush();
+    flush(true);
     if (active) counts[index] = (unsigned short)(total > K ? kListOverflow : total);
 }
 
