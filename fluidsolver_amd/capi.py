@@ -30,7 +30,7 @@ EXPORTS = (
     "fsa_rigid_particle_volume", "fsa_step", "fsa_readback_pos_color", "fsa_get_buffer", "fsa_set_buffer",
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant", "fsa_set_neighbour_lists",
     "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned", "fsa_slab_export_owned",
-    "fsa_set_scene_has_rigid",
+    "fsa_set_scene_has_rigid", "fsa_sort_particle_static",
     "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
     "fsa_solve_divergence_stiff", "fsa_apply_pstiff", "fsa_update_position", "fsa_update_velocities",
     "fsa_correct_density_error", "fsa_correct_divergence_error", "fsa_setup_dfsph", "fsa_step_dfsph",
@@ -137,6 +137,7 @@ def load() -> C.CDLL:
         "fsa_slab_set_owned": [H, C.POINTER(C.c_int)],
         "fsa_slab_export_owned": [H, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)],
         "fsa_set_scene_has_rigid": [H, C.c_int],
+        "fsa_sort_particle_static": [P, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
         "fsa_compute_density_alpha": [H], "fsa_compute_non_pressure_force": [H], "fsa_solve_density_stiff": [H],
         "fsa_solve_divergence_stiff": [H], "fsa_apply_pstiff": [H], "fsa_update_position": [H],
         "fsa_update_velocities": [H], "fsa_setup_dfsph": [H], "fsa_step_dfsph": [H, C.c_int],
@@ -199,6 +200,17 @@ def make_params(precision=PRECISION_F32, *, spacing, smoothratio, vmin, vmax, gr
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+SORT_STATIC_MAX_PARTICLES = 1 << 20
+SORT_STATIC_MAX_CELLS = 1 << 20
+
+
+def sort_particle_static(params: Params, n: int, pos3_ptr: int, hash_ptr: int, index_ptr: int, device: int = 0,
+                         stream_ptr: int = 0) -> None:
+    """fsa_sort_particle_static: the pointers are device addresses (n x 3 floats in, n ints out twice)."""
+    check(load().fsa_sort_particle_static(C.byref(params), int(device), C.c_void_p(stream_ptr), int(n),
+                                          C.c_void_p(pos3_ptr), C.c_void_p(hash_ptr), C.c_void_p(index_ptr)))
 
 
 # name -> (kind, per-particle width); kind r = real, i = int, c = per-cell int

@@ -87,7 +87,9 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.big = nullptr;
 }
 
-static int check_params(const fsa_params *p) {
+void make_dev_params(const fsa_params &h, DevParams<float> &d) { to_dev_params(h, d); }
+
+int check_params(const fsa_params *p) {
     if (!p) return fail(FSA_ERR_INVALID, "params is NULL");
     for (int a = 0; a < 3; a++)
         if (p->gridres[a] <= 0) return fail(FSA_ERR_INVALID, "gridres[%d] = %d must be positive", a, p->gridres[a]);

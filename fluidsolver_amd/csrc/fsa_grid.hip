@@ -14,6 +14,7 @@
 //   4. rank         : inside each cell, rank = number of entries with a smaller source index, which
 //                     turns the arbitrary arrival order into the stable one, deterministically.
 //   5. reorder      : gather the hot arrays through the permutation into the other buffer copy.
+#include <mutex>
 #include <utility>
 
 #include "fsa_solver.h"
@@ -24,8 +25,9 @@ namespace fsa {
 // ------------------------------------------------------------------------------------------------
 // 1. hash + count
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, const Vec4<T> *__restrict__ posType,
+// PosT: Vec4<T> ({x, y, z, type bits}, the solver's layout) or Vec3<T> (the reference's cfloat3 layout)
+template <typename T, typename PosT>
+__global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, const PosT *__restrict__ posType,
                                                             int n, int *__restrict__ hash, int *__restrict__ slot,
                                                             int *__restrict__ cellCount,
                                                             int *__restrict__ undefBlockCount) {
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, cons
     const bool valid = i < n;
     unsigned h = 0;
     if (valid) {
-        Vec4<T> p = posType[i];
+        const PosT p = posType[i];
         if (!in_domain(P, p.x, p.y, p.z)) {
             h = FSA_GRID_UNDEF;
         } else {
@@ -329,11 +331,11 @@ int launch_hash_count(Solver *s) {
     if (n == 0) return FSA_OK;
     ScopedTimer t(s, "hash_count");
     if (s->precision == FSA_PRECISION_F32)
-        hipLaunchKernelGGL(hash_count_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, s->pf,
+        hipLaunchKernelGGL((hash_count_kernel<float, float4>), dim3(nb), dim3(kBlock), 0, s->stream, s->pf,
                            (const float4 *)s->b.posType[s->cur], n, s->b.hash, s->b.slot, s->b.cellCount,
                            s->b.undefBlockCount);
     else
-        hipLaunchKernelGGL(hash_count_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, s->pd,
+        hipLaunchKernelGGL((hash_count_kernel<double, double4>), dim3(nb), dim3(kBlock), 0, s->stream, s->pd,
                            (const double4 *)s->b.posType[s->cur], n, s->b.hash, s->b.slot, s->b.cellCount,
                            s->b.undefBlockCount);
     FSA_HIP(hipGetLastError());
@@ -417,4 +419,88 @@ int launch_index_table(Solver *s) {
     return FSA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// calcHash + sortParticle on caller-owned device arrays, for callers that cannot allocate
+// ------------------------------------------------------------------------------------------------
+// Everything the counting sort needs beyond its input and its two outputs lives in one file-scope device
+// array: every GPU the library runs on holds a copy of it (at its own address) until the process ends.
+constexpr int kStaticMaxParticles = FSA_SORT_STATIC_MAX_PARTICLES;
+constexpr int kStaticMaxCells = FSA_SORT_STATIC_MAX_CELLS;
+constexpr size_t kStaticCells = (size_t)kStaticMaxCells + 8;                       // cellCount, cellStart
+constexpr size_t kStaticBlocks = (size_t)kStaticMaxParticles / kBlock + 8;         // undefBlockCount / Start
+constexpr size_t kStaticTiles = kStaticCells / kScanTile + 8;                      // scan tile sums
+constexpr size_t kStaticInts = 2 * kStaticCells + 2 * (size_t)kStaticMaxParticles + 2 * kStaticBlocks + kStaticTiles;
+static __device__ __align__(256) int scratch[kStaticInts];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static int *g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each GPU, looked up once per GPU
+
+// The device address of this GPU's copy of `scratch` (the array's name is only a host-side handle).
+static int static_scratch(int device, int **out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        FSA_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(FSA_ERR_HIP, "hipGetSymbolAddress gave a null address on device %d", device);
+        g_scratch_ptr[device] = (int *)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return FSA_OK;
+}
+
 }  // namespace fsa
+
+using namespace fsa;
+
+extern "C" int fsa_sort_particle_static(const fsa_params *p, int device, void *hip_stream, int n, const void *d_pos3,
+                                        int *d_particleHash, int *d_particleIndex) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n < 0 || n > kStaticMaxParticles)
+        return fail(FSA_ERR_CAPACITY, "n = %d: fsa_sort_particle_static takes at most %d particles", n,
+                    kStaticMaxParticles);
+    DevParams<float> P;
+    make_dev_params(*p, P);
+    if (P.num_cells > kStaticMaxCells)
+        return fail(FSA_ERR_CAPACITY, "%d cells: fsa_sort_particle_static takes at most %d", P.num_cells,
+                    kStaticMaxCells);
+    if (n > 0 && (!d_pos3 || !d_particleHash || !d_particleIndex)) return fail(FSA_ERR_INVALID, "NULL device array");
+    int ndev = 0;
+    FSA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(FSA_ERR_INVALID, "device %d of %d", device, ndev);
+    FSA_HIP(hipSetDevice(device));
+    if (n == 0) return FSA_OK;
+    int *base = nullptr;
+    rc = static_scratch(device, &base);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+
+    // carve the scratch array; the two outputs double as hash[] / slot[] until the scatter has read them
+    const int C = P.num_cells, nb = (n + kBlock - 1) / kBlock;
+    int *cellCount = base, *cellStart = cellCount + kStaticCells;
+    int *tmpIndex = cellStart + kStaticCells, *tmpHash = tmpIndex + kStaticMaxParticles;
+    int *undefBlockCount = tmpHash + kStaticMaxParticles, *undefBlockStart = undefBlockCount + kStaticBlocks;
+    int *scanTmp = undefBlockStart + kStaticBlocks;
+    int *hash = d_particleHash, *slot = d_particleIndex;
+
+    // the array keeps the previous call's contents: the counts must start at zero, the rest is overwritten
+    FSA_HIP(hipMemsetAsync(cellCount, 0, (size_t)C * sizeof(int), st));
+    hipLaunchKernelGGL((hash_count_kernel<float, Vec3<float>>), dim3(nb), dim3(kBlock), 0, st, P,
+                       (const Vec3<float> *)d_pos3, n, hash, slot, cellCount, undefBlockCount);
+    const int tilesC = (C + 1 + kScanTile - 1) / kScanTile, tilesU = (nb + 1 + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tilesC), dim3(kBlock), 0, st, cellCount, C, scanTmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, scanTmp, tilesC);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(tilesC), dim3(kBlock), 0, st, cellCount, C, scanTmp, cellStart);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(tilesU), dim3(kBlock), 0, st, undefBlockCount, nb, scanTmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, scanTmp, tilesU);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(tilesU), dim3(kBlock), 0, st, undefBlockCount, nb, scanTmp,
+                       undefBlockStart);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(kBlock), 0, st, n, C, hash, slot, cellStart, undefBlockStart,
+                       tmpIndex, tmpHash);
+    hipLaunchKernelGGL(rank_kernel, dim3(nb), dim3(kBlock), 0, st, n, tmpIndex, tmpHash, cellStart, d_particleIndex,
+                       d_particleHash);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}

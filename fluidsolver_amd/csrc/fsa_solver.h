@@ -119,6 +119,9 @@ struct Solver {
 
 // Sets the calling thread's error message and returns `code`.
 int fail(int code, const char *fmt, ...);
+// Argument check of a caller's parameter block, and its fp32 device form (fsa_capi.hip).
+int check_params(const fsa_params *p);
+void make_dev_params(const fsa_params &h, DevParams<float> &d);
 
 #define FSA_HIP(expr)                                                                               \
     do {                                                                                            \

@@ -266,6 +266,27 @@ int fsa_setup_iisph(fsa_solver *s);
 /* nsteps x SolveIISPH without the host read-back of positions */
 int fsa_step_iisph(fsa_solver *s, int nsteps);
 
+/* ---- counting sort without any allocation --------------------------------
+ *
+ * No counterpart in the reference.  For callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc -- this is fsa_calc_hash + fsa_sort_particle
+ * (calcHash + sortParticle, solver/sph_solver.cu:30-53) on the caller's own device arrays, fp32: d_pos3 holds
+ * n positions in the cfloat3 layout; afterwards d_particleHash is sorted ascending (GRID_UNDEF last) and
+ * d_particleIndex is the stable permutation, bit for bit what the two solver calls give.  The grid comes from
+ * *p (dx, gridxmin/max, gridres, slab_z0/slab_nz).  Work is queued on hip_stream (NULL = the default stream)
+ * of `device`; nothing is synchronised.
+ *
+ * The call allocates nothing: the cell counts, their prefix sums and the cell-grouped intermediate order
+ * live in a fixed device array inside the library (about 17 MB, held on every GPU the library runs on until
+ * the process ends).  Hence the limits: n <= FSA_SORT_STATIC_MAX_PARTICLES and gridres[0] * gridres[1] *
+ * layers <= FSA_SORT_STATIC_MAX_CELLS, beyond which the call fails with FSA_ERR_CAPACITY.  All calls on one
+ * GPU share that array: calls that overlap on one GPU (two streams, two threads) race.
+ */
+#define FSA_SORT_STATIC_MAX_PARTICLES 1048576
+#define FSA_SORT_STATIC_MAX_CELLS 1048576
+int fsa_sort_particle_static(const fsa_params *p, int device, void *hip_stream, int n, const void *d_pos3,
+                             int *d_particleHash, int *d_particleIndex);
+
 /* ---- measurement ------------------------------------------------------ */
 #define FSA_KERNEL_NAME_MAX 32
 typedef struct fsa_kernel_time {
