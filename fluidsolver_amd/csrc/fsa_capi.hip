@@ -8,6 +8,7 @@
 #include <new>
 
 #include "fsa_solver.h"
+#include "fsa_tile.h"
 
 namespace fsa {
 
@@ -116,7 +117,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.nbList, b.nbCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -165,6 +166,7 @@ static void invalidate_order(Solver *s) {
     s->index_table_valid = s->ref_cells_valid = false;
     s->pd_valid = false;
     s->lists_valid = false;
+    s->hits_valid = false;
 }
 
 }  // namespace fsa
@@ -292,6 +294,10 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.gridCellEnd, C * sizeof(int), true);
     ALLOC(b.blockRows, (nblocks + 8) * 20 * sizeof(int), true);
     ALLOC(b.bigBlocks, (nblocks + 8) * sizeof(int), true);
+    if (precision == FSA_PRECISION_F32) {  // recorded hits of the WCSPH passes (fsa_sph_fast.hip)
+        ALLOC(b.hitWords, (nblocks + 8) * kHitSlots * kTunedBS * 8, false);
+        ALLOC(b.hitCount, (nblocks + 8) * kTunedBS, true);
+    }
     ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
     ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);
     ALLOC(b.undefBlockStart, (nblocks + 8) * sizeof(int), true);
@@ -506,6 +512,7 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
     s->owned_from_sort = true;
     s->pd_valid = false;
     s->lists_valid = false;
+    s->hits_valid = false;
     s->hash_valid = false;  // hash[] described the previous order
     s->perm_valid = false;
     s->index_table_valid = false;
@@ -725,6 +732,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     FSA_HIP(hipStreamSynchronize(s->stream));
     s->pd_valid = false;  // density, pressure, mass or viscosity may change under it
     s->lists_valid = false;
+    s->hits_valid = false;
     auto plain = [&](void *ddst, size_t expect) -> int {
         TRY(want(expect));
         if (bytes) FSA_HIP(hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice));
@@ -1123,7 +1131,7 @@ int fsa_debug_time_pass(fsa_solver *hs, int which, int ablate, int reps) {
 int fsa_set_variant(fsa_solver *hs, int variant) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
-    if (variant < 0 || variant > 2) return fail(FSA_ERR_INVALID, "unknown variant %d", variant);
+    if (variant < 0 || variant > 3) return fail(FSA_ERR_INVALID, "unknown variant %d", variant);
     s->variant = variant;
     return FSA_OK;
 }

@@ -442,6 +442,7 @@ int launch_update_position(Solver *s) {
     if (s->n == 0) return FSA_OK;
     ScopedTimer t(s, "update_position");
     s->lists_valid = false;  // positions move
+    s->hits_valid = false;
     DF_DISPATCH(update_position_kernel, (Vec4<T> *)s->b.posType[s->cur], (const Vec3<T> *)s->b.v_star);
     return FSA_OK;
 }

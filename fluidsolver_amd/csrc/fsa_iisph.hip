@@ -772,6 +772,7 @@ int launch_iisph_integrate(Solver *s) {
     if (s->n == 0) return FSA_OK;
     ScopedTimer t(s, "iisph_integrate");
     s->lists_valid = false;  // positions move
+    s->hits_valid = false;
     const int c = s->cur;
     DF_DISPATCH(iisph_integrate_kernel, (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
                 (const Vec3<T> *)s->b.v_star, (const Vec3<T> *)s->b.pressureForce);

@@ -60,6 +60,8 @@ struct Buffers {
     int *bigBlocks = nullptr;    // count, then ids of the blocks that need the large tiles
     unsigned short *nbList = nullptr;   // recorded neighbour lists (allocated on first use), see fsa_tile.h
     unsigned short *nbCount = nullptr;  // entries per particle
+    void *hitWords = nullptr;           // recorded hits of the WCSPH passes (fp32), see fsa_tile.h
+    unsigned char *hitCount = nullptr;  // words per particle
     int *scanTmp = nullptr;
     int *undefBlockCount = nullptr;
     int *undefBlockStart = nullptr;
@@ -102,6 +104,7 @@ struct Solver {
     bool pd_fast = false;   // ... in the fast flavour's layout
     bool use_lists = true;      // passes that repeat between two sorts replay recorded neighbour lists
     bool lists_valid = false;   // nbList / nbCount describe the current arrays and positions
+    bool hits_valid = false;    // hitWords / hitCount describe the current arrays and positions
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
@@ -171,6 +174,8 @@ int launch_iisph_integrate(Solver *s);
 int launch_mean_error(Solver *s, double *out);  // synchronises
 int ensure_lists(Solver *s);  // builds the neighbour lists if they are enabled and stale
 int launch_density_tuned(Solver *s);
+int launch_density_fast(Solver *s);
+int launch_force_fast(Solver *s);
 int launch_density_rigid_tuned(Solver *s);
 int launch_force_tuned(Solver *s);
 int debug_time_pass(Solver *s, int which, int ablate, int reps);

@@ -270,6 +270,7 @@ int launch_advect(Solver *s) {
     if (s->n == 0) return FSA_OK;
     ScopedTimer t(s, "advect");
     s->lists_valid = false;  // positions move
+    s->hits_valid = false;
     const int c = s->cur;
     FSA_DISPATCH(advect_kernel, s->n, P, s->n, (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
                  (const Vec3<T> *)s->b.force, (Vec3<T> *)s->b.v_star);

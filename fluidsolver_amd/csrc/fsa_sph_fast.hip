@@ -1,0 +1,540 @@
+// Fast fp32 density and force passes for gfx950 (kernel variant 2): one neighbour search per step.
+//
+// The two passes of a WCSPH step look at the same positions, so the search runs once:
+//
+//   density: a workgroup owns 256 consecutive particles of the sorted arrays; the nine neighbour rows stream
+//            through double-buffered LDS tiles kept as separate x / y / z arrays (as in fsa_sph_tuned.hip);
+//            every lane walks its own index range of a row in aligned groups of four candidates, appends the
+//            squared distances of the hits to its LDS queue for the kernel evaluation, and also keeps ONE BIT
+//            per candidate in a register (one add-with-carry per candidate).  Every eight groups, and at the
+//            end of a row, the word goes to global memory as {mask, index of its first candidate} if it has a
+//            bit set: 8 bytes per 32 candidates.
+//   force  : no search.  The rows stream through LDS again, this time with everything a pair needs
+//            ({x, y, z, m}, {v, p/rho^2}, viscosity term: 36 bytes per particle, coalesced loads), and every
+//            lane walks the set bits of its recorded words for the row at hand and reads its neighbours from
+//            the tile.  Gathering neighbours from global memory instead costs a wavefront one cache-line
+//            look-up per distinct line and instruction (~30 per gather), several times the LDS reads.
+//
+// Words are stored per workgroup as [slot][lane] (a wavefront writes and reads 512 contiguous bytes per
+// slot), at most kHitSlots per particle; a particle that needs more, or whose block cannot be tiled, is
+// marked and walks the cells in the replay kernels with the same pair arithmetic in the same order.
+// Sums run in the reference's neighbour order (rows z, y; ascending index; TYPE_BOUNDARY neighbours of the
+// force pass summed apart), so a particle's result depends neither on the tile alignment nor on which
+// particles share its workgroup.  Arithmetic of the pairs: cubic_fast / force_pair_fast (hardware sqrt /
+// rsq / rcp, fused multiply-adds), about 1e-7 relative per pair term away from the exact flavour.
+#include <type_traits>
+
+#include "fsa_fast.h"
+#include "fsa_pair.h"
+#include "fsa_solver.h"
+#include "fsa_tile.h"
+
+namespace fsa {
+
+// ------------------------------------------------------------------------------------------------
+// density + pressure + hit record (scenes without TYPE_RIGID particles: only fluid neighbours count)
+// ------------------------------------------------------------------------------------------------
+// EVAL = false: only the record (for a force pass that is not preceded by this solver's density pass).
+template <int BS, int ROWCAP, int Q, bool EVAL>
+__global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, int n,
+                                                            const float4 *__restrict__ posType,
+                                                            const float4 *__restrict__ velMass,
+                                                            const float *__restrict__ restDensity,
+                                                            const int *__restrict__ cellStart,
+                                                            const int *__restrict__ sortedHash,
+                                                            uint2 *__restrict__ hitWords,
+                                                            unsigned char *__restrict__ hitCount,
+                                                            float *__restrict__ density,
+                                                            float *__restrict__ pressure,
+                                                            float2 *__restrict__ pd, int run_log) {
+    using Shared = RowShared<BS, ROWCAP, false>;
+    __shared__ Shared sh;
+    __shared__ Segments sg;
+    __shared__ int wallSeg[kMaxSegs];  // does the segment hold a TYPE_BOUNDARY particle?
+    // which entries of a tile are TYPE_BOUNDARY particles, one bit each (entry 32 w + b at bit b of word w)
+    constexpr int kWallWords = row_regs<BS, ROWCAP>() * BS / 32 + 1;
+    __shared__ unsigned wallBits[2][kWallWords];
+    __shared__ float queue[EVAL ? Q * BS : 1];
+    const int tid = threadIdx.x;
+    const int dbg = run_log >> 8;
+    run_log &= 255;
+    const int blk = xcd_block(run_log);
+    const int b0 = blk * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int nb = min(BS, n - b0);
+    const int index = b0 + tid;
+    const bool active = index < n;
+    unsigned hlo = 0, hhi = 0;
+    if (!P.rows || P.nz != P.gres[2]) {  // slab runs: a tile that lies entirely in the outer halo layer feeds nobody
+        hlo = (unsigned)sortedHash[b0];
+        hhi = (unsigned)sortedHash[b0 + nb - 1];
+        if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
+    }
+    if (tid < kMaxSegs) wallSeg[tid] = 0;
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    const bool staged = cls != 0;
+    if (staged) setup_segments<ROWCAP>(sh, cls, sg);
+
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mass_i = 0.f, rd_i = 1.f;
+    if (active) {
+        pi = posType[index];
+        if (EVAL) {
+            mass_i = velMass[index].w;
+            rd_i = restDensity[index];
+        }
+    }
+    const float sr = P.sr, sr2 = sr * sr;
+    const float h = (float)((double)sr * 0.5);
+    const float inv_h = 1.0f / h, kcubic = P.kernel_cubic;
+    float dens = 0.f;
+    int words = kHitOverflow;  // an untiled block: the force pass walks the cells for its particles, too
+    if (!staged) {
+        if (EVAL && active) dens = density_walk_global_fast(P, pi, mass_i, posType, cellStart);
+    } else {
+        const bool fluid_i = active && unpack_int(pi.w) == FSA_TYPE_FLUID;
+        const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
+        uint2 *const out = hitWords + (size_t)blk * kHitSlots * BS + tid;
+        float *const q = queue + (EVAL ? tid : 0);
+        int cnt = 0;  // entries in the queue
+        words = 0;
+        auto drain = [&]() {
+            if (dbg & 2) { cnt = 0; return; }
+            for (int s = 0; wave_any(s < cnt); s += kChunk) {
+                float d2[kChunk];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) d2[u] = q[(s + u) * BS];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    const float w = s + u < cnt ? cubic_fast(d2[u], inv_h, kcubic) : 0.0f;
+                    dens = __builtin_fmaf(mass_i, w, dens);
+                }
+            }
+            cnt = 0;
+        };
+        // One tile, in two steps so that the loads stay in flight during the cull of the tile before: issue ...
+        auto fetch = [&](int s, int len, float4(&e)[row_regs<BS, ROWCAP>()]) {
+            const int last = len > 0 ? len - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < row_regs<BS, ROWCAP>(); k++) e[k] = posType[s + min(tid + k * BS, last)];
+        };
+        // ... and finish: everything that is not a fluid particle is moved far away, so the cull needs no type
+        // test; the TYPE_BOUNDARY entries are noted in wallBits[buf].  True if there is one.
+        auto finish = [&](int buf, int len, float4(&e)[row_regs<BS, ROWCAP>()]) -> bool {
+            bool wall = false;
+#pragma unroll
+            for (int k = 0; k < row_regs<BS, ROWCAP>(); k++) {
+                const int t = tid + k * BS < len ? unpack_int(e[k].w) : -1;
+                const unsigned long long wb = __ballot(t == FSA_TYPE_BOUNDARY);
+                if ((tid & 63) == 0) {
+                    wallBits[buf][(tid + k * BS) >> 5] = (unsigned)wb;
+                    wallBits[buf][((tid + k * BS) >> 5) + 1] = (unsigned)(wb >> 32);
+                }
+                wall |= wb != 0ull;
+                if (t != FSA_TYPE_FLUID) e[k] = make_float4(kFar, kFar, kFar, 0.0f);
+            }
+            return wall;
+        };
+        // the lane's index range inside a segment, likewise: the two cell-table loads now, the arithmetic later
+        auto range_issue = [&](int row, int &c0, int &c1) {
+            c0 = c1 = 0;
+            if (active) {
+                const int c = walk.row_cell(P, row % 3 - 1, row / 3 - 1);
+                if (c >= 0) {
+                    c0 = cellStart[c];
+                    c1 = cellStart[c + (walk.xhi - walk.xlo) + 1];
+                }
+            }
+        };
+        auto range_finish = [&](int c0, int c1, int seg_first, int len, int &a, int &b) {
+            a = min(max(c0 - seg_first, 0), len);
+            b = min(max(c1 - seg_first, 0), len);
+            if (c1 <= c0) a = b = 0;
+        };
+        // A word of the record: 32 candidates of segment `seg` from candidate `first` on.
+        auto put_word = [&](unsigned m, unsigned meta) {
+            if (m) {
+                if (words < kHitExtra && !(dbg & 1)) out[(size_t)(kMaxSegs + words) * BS] = make_uint2(m, meta);
+                words++;
+            }
+        };
+
+        float4 e[row_regs<BS, ROWCAP>()];
+        int lj, le, nlj = 0, nle = 0;
+        int rc0, rc1;
+        const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
+        fetch(sh.rowStartG[0], len0, e);
+        range_issue(0, rc0, rc1);
+        bool wall = finish(0, len0, e);
+        range_finish(rc0, rc1, sh.rowStartG[0], len0, lj, le);
+        row_store<BS, ROWCAP, false>(sh, 0, e);
+        __syncthreads();  // wallSeg cleared, segment table written
+        if (wall) wallSeg[0] = 1;
+        __syncthreads();
+        const int nseg = sg.count;
+        for (int r = 0; r < nseg; r++) {
+            const int buf = r & 1;
+            if (r + 1 < nseg) {  // in flight during the cull below
+                fetch(sg.start[r + 1], sg.len[r + 1], e);
+                range_issue(sg.row[r + 1], rc0, rc1);
+            }
+            // The aligned groups of four that cover [lj, le).  Candidates of the first and the last group outside
+            // the range belong to other cells and must not count (with empty cells in between they can be the
+            // lane's neighbours of ANOTHER row), so those two groups test the range per candidate.  All lanes take
+            // their first group in the same trip and the following ones in step; a lane that runs out examines
+            // far-away padding until the others are done, and the last (partial) groups come in one trip of
+            // their own at the end.
+            //
+            // Record: four hit bits per trip are shifted into c2:c1:c0 in every lane (96 bits: nothing is
+            // written inside the cull -- a store issued there would make the wait for the next tile a wait for
+            // the store as well), so bit k from the top belongs to candidate 4 * (lj >> 2) + k; the bits of the
+            // last partial group are kept apart and put in their place afterwards.
+            unsigned c0 = 0, c1 = 0, c2 = 0, hl = 0;
+            int trips = 0;  // the same in every lane
+            auto cull_group = [&](bool go, int g, int lo, int hi, auto masked_tag) -> unsigned {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                const int gg = go ? g : Shared::kPad;
+                float d2[kChunk];
+                group_d2<true>(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], pi.x, pi.y, pi.z, d2);
+                unsigned h4 = 0;
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    const unsigned hit = (d2[u] < sr2 && (!MASKED || (u >= lo && u < hi))) ? 1u : 0u;
+                    if (EVAL) {
+                        q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
+                        cnt += (int)hit;
+                    }
+                    h4 = h4 + h4 + hit;
+                }
+                return h4;
+            };
+            auto shift_in = [&](unsigned h4) {
+                c2 = __funnelshift_l(c1, c2, 4);
+                c1 = __funnelshift_l(c0, c1, 4);
+                c0 = (c0 << 4) | h4;
+                trips++;
+            };
+            const bool has = lj < le;
+            const int g0 = lj >> 2;
+            int base = lj & ~(kChunk - 1);
+            if (wave_any(has)) {  // first group
+                shift_in(cull_group(has, g0, lj - base, le - base, std::true_type()));
+                if (EVAL && wave_any(cnt > Q - kChunk)) drain();
+            }
+            base = has ? base + kChunk : le;
+            while (wave_any(base + kChunk <= le)) {  // whole groups
+                const bool go = base + kChunk <= le;
+                shift_in(cull_group(go, base >> 2, 0, kChunk, std::false_type()));
+                base += go ? kChunk : 0;
+                if (EVAL && wave_any(cnt > Q - kChunk)) drain();
+            }
+            if (wave_any(base < le)) {  // last group
+                hl = cull_group(base < le, base >> 2, 0, le - base, std::true_type());
+                if (EVAL && wave_any(cnt > Q - kChunk)) drain();
+            }
+            const bool walls_here = wallSeg[r] != 0;
+            if (r + 1 < nseg) {
+                wall = finish(buf ^ 1, sg.len[r + 1], e);
+                range_finish(rc0, rc1, sg.start[r + 1], sg.len[r + 1], nlj, nle);
+                row_store<BS, ROWCAP, false>(sh, buf ^ 1, e);
+                if (wall) wallSeg[r + 1] = 1;
+            }
+            {
+                // left-align the 4 * trips bits in the 96 (first candidate at bit 31 of c2): trips <= 24 here, a
+                // segment of more groups per lane has lost its oldest bits and the lane gives up its record
+                const int sft = 96 - 4 * min(trips, 24), ws = sft >> 5, t = sft & 31;
+                if (ws >= 2) {
+                    c2 = c0;
+                    c1 = c0 = 0;
+                } else if (ws == 1) {
+                    c2 = c1;
+                    c1 = c0;
+                    c0 = 0;
+                }
+                c2 = __funnelshift_l(c1, c2, t);
+                c1 = __funnelshift_l(c0, c1, t);
+                c0 <<= t;
+                // the last partial group, (base >> 2) - g0 groups from the start
+                const int off = 4 * ((base >> 2) - g0);
+                const unsigned hv = off < 96 ? hl << (28 - (off & 31)) : 0u;
+                c2 |= off < 32 ? hv : 0u;
+                c1 |= (off >= 32 && off < 64) ? hv : 0u;
+                c0 |= off >= 64 ? hv : 0u;
+                const unsigned meta = ((unsigned)r << kHitSegShift) | (unsigned)(4 * g0);
+                // the segment's first word has a slot of its own, so that the force pass can fetch it ahead
+                if (!(dbg & 1)) out[(size_t)r * BS] = make_uint2(c2, meta);
+                put_word(c1, meta + 32);
+                put_word(c0, meta + 64);
+                if (trips > 24 || (hl && off >= 96)) words = kHitSlots + 1;  // no record for this particle
+            }
+            // TYPE_BOUNDARY neighbours count for fluid particles wherever they are in the 27 cells (ForceCell has
+            // no range test on that branch): words of their own, flagged, after the segment's fluid words
+            if (walls_here) {
+                for (int c0 = lj; wave_any(fluid_i && c0 < le); c0 += 32) {
+                    unsigned m = 0;
+                    if (fluid_i && c0 < le) {
+                        const int wi = c0 >> 5, sh = c0 & 31;
+                        unsigned bits = wallBits[buf][wi] >> sh;  // candidate c0 + b at bit b
+                        if (sh) bits |= wallBits[buf][wi + 1] << (32 - sh);
+                        if (le - c0 < 32) bits &= (1u << (le - c0)) - 1u;
+                        m = __brev(bits);  // first candidate highest
+                    }
+                    put_word(m, kHitWallFlag | ((unsigned)r << kHitSegShift) | (unsigned)c0);
+                }
+            }
+            if (r + 1 < nseg) {
+                lj = nlj;
+                le = nle;
+                __syncthreads();  // segment r + 1 visible; everyone is done with the buffer of segment r - 1
+            }
+        }
+        if (EVAL) drain();
+        if (words > kHitExtra) words = kHitOverflow;
+    }
+    if (active) {
+        hitCount[index] = (unsigned char)words;
+        if (EVAL) {
+            density[index] = dens;
+            float pr = P.pressureK * (r_pow(dens / rd_i, 7.0f) - 1);
+            if (pr < 0) pr = 0;
+            pressure[index] = pr;
+            // the per-particle terms of the force pass, while they are at hand
+            pd[index] = make_float2(pr / dens / dens, mass_i / dens * 2.0f * P.viscosity);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// force: replay of the recorded hits from full-data row tiles
+// ------------------------------------------------------------------------------------------------
+template <int ROWCAP> struct PairTile {
+    float4 A[2][ROWCAP];  // x, y, z, mass
+    float4 B[2][ROWCAP];  // velocity, pressure / density^2
+    float C[2][ROWCAP];   // mass / density * 2 * viscosity
+};
+
+template <int BS, int ROWCAP>
+__global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int n,
+                                                        const float4 *__restrict__ posType,
+                                                        const float4 *__restrict__ velMass,
+                                                        const float2 *__restrict__ pd,
+                                                        const int *__restrict__ cellStart,
+                                                        const int *__restrict__ sortedHash,
+                                                        const uint2 *__restrict__ hitWords,
+                                                        const unsigned char *__restrict__ hitCount,
+                                                        Vec3<float> *__restrict__ force, int run_log) {
+    using Shared = RowShared<1, 4, false>;  // only its row table is used here
+    __shared__ Shared sh;
+    __shared__ Segments sg;
+    __shared__ PairTile<ROWCAP> tile;
+    const int tid = threadIdx.x;
+    const int dbg = run_log >> 8;
+    run_log &= 255;
+    const int blk = xcd_block(run_log);
+    const int b0 = blk * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int nb = min(BS, n - b0);
+    const int index = b0 + tid;
+    unsigned hlo = 0, hhi = 0;
+    if (!P.rows || P.nz != P.gres[2]) {  // slab runs: forces are only needed for the layers the solver owns
+        hlo = (unsigned)sortedHash[b0];
+        hhi = (unsigned)sortedHash[b0 + nb - 1];
+        if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 0)) return;
+    }
+    ForceSelf<float> S;
+    S.p = make_float4(0.f, 0.f, 0.f, 0.f);
+    S.v = S.p;
+    S.pterm = 0.f;
+    S.fx = S.fy = S.fz = 0.f;
+    bool active = index < n;
+    if (active) {
+        S.p = posType[index];
+        active = unpack_int(S.p.w) == FSA_TYPE_FLUID;  // other types keep force[index] as it is
+    }
+    // a block without fluid particles (wall layers) has nothing to do
+    if (!__syncthreads_or(active ? 1 : 0)) return;
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
+    const bool staged = cls != 0;
+    if (staged) setup_segments<ROWCAP>(sh, cls, sg);
+    int cnt = 0;       // extra words of the lane's record
+    bool rec = false;  // the lane has a record
+    if (active) {
+        S.v = velMass[index];
+        S.pterm = pd[index].x;
+        cnt = hitCount[index];
+        rec = cnt != kHitOverflow && !(dbg & 4);
+    }
+    // wall neighbours are summed on their own (the reference's arithmetic) and added at the end
+    ForceSelf<float> Sb = S;
+    const float sr = P.sr, sr2 = sr * sr;
+    const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+    if (cnt == kHitOverflow) force_walk_global_fast(P, index, S, Sb, posType, velMass, pd, cellStart);
+    if (!rec) cnt = 0;
+    if (staged) {
+        const uint2 *const wp = hitWords + (size_t)blk * kHitSlots * BS + tid;
+        int w = 0;  // extra words taken so far
+        uint2 nxt = cnt > 0 ? wp[(size_t)kMaxSegs * BS] : make_uint2(0u, 0u);
+        uint2 fw = wp[0];  // the first word of the segment at hand (a slot per segment: fetched a segment ahead)
+        struct Stage {
+            float4 p, v;
+            float2 a;
+        };
+        auto fetch = [&](int s, int len, Stage(&e)[row_regs<BS, ROWCAP - kChunk>()]) {
+            const int last = len > 0 ? len - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < row_regs<BS, ROWCAP - kChunk>(); k++) {
+                const int j = s + min(tid + k * BS, last);
+                e[k].p = posType[j];
+                e[k].v = velMass[j];
+                e[k].a = pd[j];
+            }
+        };
+        auto store = [&](int buf, int len, const Stage(&e)[row_regs<BS, ROWCAP - kChunk>()]) {
+#pragma unroll
+            for (int k = 0; k < row_regs<BS, ROWCAP - kChunk>(); k++) {
+                const int i = tid + k * BS;
+                if (i < len) {
+                    tile.A[buf][i] = make_float4(e[k].p.x, e[k].p.y, e[k].p.z, e[k].v.w);
+                    tile.B[buf][i] = make_float4(e[k].v.x, e[k].v.y, e[k].v.z, e[k].a.x);
+                    tile.C[buf][i] = e[k].a.y;
+                }
+            }
+        };
+        Stage e[row_regs<BS, ROWCAP - kChunk>()];
+        const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
+        fetch(sh.rowStartG[0], len0, e);
+        store(0, len0, e);
+        __syncthreads();
+        const int nseg = sg.count;
+        for (int r = 0; r < nseg; r++) {
+            const int buf = r & 1;
+            const int seg_start = sg.start[r];
+            int nlen = 0;
+            uint2 fwn = make_uint2(0u, 0u);
+            if (r + 1 < nseg) {  // in flight during the replay below
+                nlen = sg.len[r + 1];
+                if (!(dbg & 2)) fetch(sg.start[r + 1], nlen, e);
+                fwn = wp[(size_t)(r + 1) * BS];
+            }
+            // the lane's words of this segment, in order; `cur` only ever holds bits of the segment at hand
+            unsigned cur = rec ? fw.x : 0u;
+            int base = (int)(fw.y & ((1u << kHitSegShift) - 1u));  // candidate at bit 31, as an index into the tile
+            bool wallw = false;
+            struct Nb {
+                bool has, wall;
+                int j;
+                float4 a, b;
+                float c;
+            };
+            auto next = [&](Nb &N) {
+                if (cur == 0 && w < cnt && (int)((nxt.y & ~kHitWallFlag) >> kHitSegShift) == r) {
+                    cur = nxt.x;
+                    base = (int)(nxt.y & ((1u << kHitSegShift) - 1u));
+                    wallw = (nxt.y & kHitWallFlag) != 0;
+                    w++;
+                    if (w < cnt) nxt = wp[(size_t)(kMaxSegs + w) * BS];  // in flight until the word is used up
+                }
+                N.has = cur != 0;
+                const int k = __builtin_clz(cur | 1u);  // cur == 0: nothing to clear
+                cur &= ~(0x80000000u >> k);
+                const int t = N.has ? base + k : 0;
+                N.j = seg_start + t;
+                N.wall = N.has && wallw;
+                N.a = tile.A[buf][t];
+                N.b = tile.B[buf][t];
+                N.c = tile.C[buf][t];
+            };
+            auto eval = [&](const Nb &N) {
+                if (dbg & 1) { S.fx += N.a.x + N.b.x + N.c; return; }
+                const float xx = S.p.x - N.a.x, xy = S.p.y - N.a.y, xz = S.p.z - N.a.z;
+                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                // straight-line: an entry that does not count is evaluated anyway and zeroed by selects
+                const bool ok = N.has && !N.wall && d2 < sr2 && N.j != index;
+                force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, ok, make_float4(N.b.x, N.b.y, N.b.z, N.a.w),
+                                make_float2(N.b.w, N.c));
+                if (wave_any(N.wall)) {  // wall particles (rare): from global memory, the reference's arithmetic
+                    if (N.wall) force_pair(P, sr, sr2, Sb, false, posType[N.j], velMass[N.j], pd[N.j].x, 1.0f);
+                }
+            };
+            // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated.
+            // A lane that has run out of bits for this segment stays out until the next one.
+            Nb N0, N1;
+            next(N0);
+            while (wave_any(N0.has)) {
+                next(N1);
+                eval(N0);
+                if (!wave_any(N1.has)) break;
+                next(N0);
+                eval(N1);
+            }
+            if (r + 1 < nseg) {
+                store(buf ^ 1, nlen, e);
+                fw = fwn;
+                __syncthreads();  // segment r + 1 visible; everyone is done with the buffer of segment r - 1
+            }
+        }
+    }
+    if (active) {
+        Vec3<float> f;
+        S.fx += Sb.fx;
+        S.fy += Sb.fy;
+        S.fz += Sb.fz;
+        f.x = S.fx + 0.0f;
+        f.y = S.fy + (float)-9.8;  // the literal of solver/sph_kernel_impl.cuh:372
+        f.z = S.fz + 0.0f;
+        force[index] = f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int fast_dbg() { const char *e = getenv("FSA_FAST_DBG"); return e ? atoi(e) : 0; }
+constexpr int kQueueD = 10;  // density queue: 4-byte slots (with the tile: 19.6 KB of LDS per workgroup)
+
+static inline int tiled_grid(const Solver *s, int run_log) {
+    const int unit = kXcds << run_log;  // the grid is rounded up to whole runs
+    return ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+}
+
+template <bool EVAL> static int launch_density_record(Solver *s) {
+    const int c = s->cur, run_log = xcd_run_log() | (fast_dbg() << 8);
+    hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, run_log)),
+                       dim3(kTunedBS), 0, s->stream, s->pf, s->n, (const float4 *)s->b.posType[c],
+                       (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
+                       s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, (float *)s->b.density,
+                       (float *)s->b.pressure, (float2 *)s->b.pd, run_log);
+    FSA_HIP(hipGetLastError());
+    s->hits_valid = true;
+    return FSA_OK;
+}
+
+int launch_density_fast(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "density");
+    int rc = launch_density_record<true>(s);
+    if (rc) return rc;
+    s->pd_valid = true;
+    s->pd_fast = true;
+    return FSA_OK;
+}
+
+// needs pd[] in the fast layout (the caller sees to that)
+int launch_force_fast(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    if (!s->hits_valid) {
+        ScopedTimer t(s, "record_hits");
+        int rc = launch_density_record<false>(s);
+        if (rc) return rc;
+    }
+    ScopedTimer t(s, "force");
+    const int c = s->cur, run_log = xcd_run_log() | (fast_dbg() << 8);
+    hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, run_log)), dim3(kTunedBS), 0,
+                       s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
+                       (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
+                       s->b.hitCount, (Vec3<float> *)s->b.force, run_log);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+}  // namespace fsa

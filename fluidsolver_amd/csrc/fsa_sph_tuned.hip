@@ -33,86 +33,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "fsa_fast.h"
 #include "fsa_pair.h"
 #include "fsa_solver.h"
 #include "fsa_tile.h"
 
 namespace fsa {
-
-// ---- fast fp32 pair arithmetic -----------------------------------------------------------------
-// One fluid-fluid pair of the force pass in the fast flavour.  `ok` = the pair counts (inside the
-// support, not the particle itself, a fluid neighbour); a pair that does not count adds exact zeros.
-__device__ __forceinline__ void force_pair_fast(ForceSelf<float> &S, float sr, float kspiky, float visc_eps,
-                                                float xx, float xy, float xz, float d2, bool ok, const float4 &vj,
-                                                const float2 &aj) {
-    const float rinv = __builtin_amdgcn_rsqf(d2);
-    const float c = sr - d2 * rinv;
-    const float nablaw = kspiky * c * c * rinv;
-    const float pc = ok ? nablaw * vj.w * (aj.x + S.pterm) : 0.0f;
-    const float vc = ok ? nablaw * d2 * __builtin_amdgcn_rcpf(d2 + visc_eps) * aj.y : 0.0f;
-    S.fx = __builtin_fmaf(-xx, pc, S.fx);
-    S.fy = __builtin_fmaf(-xy, pc, S.fy);
-    S.fz = __builtin_fmaf(-xz, pc, S.fz);
-    S.fx = __builtin_fmaf(S.v.x - vj.x, vc, S.fx);
-    S.fy = __builtin_fmaf(S.v.y - vj.y, vc, S.fy);
-    S.fz = __builtin_fmaf(S.v.z - vj.z, vc, S.fz);
-}
-
-// Per-particle walks in the fast flavour, for blocks that cannot use the row tiles.  They evaluate the
-// same expressions in the same order as the tiled kernels, so a particle's result does not depend on
-// which path its block took (nor, in a slab run, on how the particles are split over solvers).
-__device__ __forceinline__ float density_walk_global_fast(const DevParams<float> &P, const float4 &pi, float mass_i,
-                                                          const float4 *__restrict__ posType,
-                                                          const int *__restrict__ cellStart) {
-    const float sr = P.sr, sr2 = sr * sr;
-    const float h = (float)((double)sr * 0.5);
-    const float inv_h = 1.0f / h, kcubic = P.kernel_cubic;
-    const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
-    float dens = 0.f;
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++) {
-            int start, end;
-            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
-            for (int j = start; j < end; j++) {
-                const float4 pj = posType[j];
-                if (unpack_int(pj.w) != FSA_TYPE_FLUID) continue;
-                const float xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                if (d2 < sr2) dens = __builtin_fmaf(mass_i, cubic_fast(d2, inv_h, kcubic), dens);
-            }
-        }
-    return dens;
-}
-
-// S collects the fluid neighbours, Sb the TYPE_BOUNDARY ones (exact arithmetic, summed separately).
-__device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P, int index, ForceSelf<float> &S,
-                                                       ForceSelf<float> &Sb, const float4 *__restrict__ posType,
-                                                       const float4 *__restrict__ velMass,
-                                                       const float2 *__restrict__ pd,
-                                                       const int *__restrict__ cellStart) {
-    const float sr = P.sr, sr2 = sr * sr;
-    const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
-    const RowWalk<float> walk(P, S.p.x, S.p.y, S.p.z);
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++) {
-            int start, end;
-            if (!walk.row(P, cellStart, dy, dz, start, end)) continue;
-            for (int j = start; j < end; j++) {
-                const float4 pj = posType[j];
-                const int tj = unpack_int(pj.w);
-                const float xx = S.p.x - pj.x, xy = S.p.y - pj.y, xz = S.p.z - pj.z;
-                if (tj == FSA_TYPE_FLUID) {
-                    const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                    if (d2 < sr2 && j != index)
-                        force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, true, velMass[j], pd[j]);
-                } else {
-                    const float d2 = xx * xx + xy * xy + xz * xz;
-                    if (force_pair_active(tj, j == index, d2, sr2))
-                        force_pair(P, sr, sr2, Sb, j == index, pj, velMass[j], pd[j].x, 1.0f);
-                }
-            }
-        }
-}
 
 static int g_ablate = 0;        // timing experiments only (debug_time_pass)
 static void *g_out0 = nullptr;  // when set, results go to these scratch arrays instead
@@ -519,6 +445,7 @@ constexpr int kQueueF = 48;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    if (s->variant == 3 && !g_out0) return launch_density_fast(s);
     ScopedTimer t(s, g_out0 ? "density_dbg" : "density");
     const int c = s->cur;
     const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
@@ -526,7 +453,7 @@ int launch_density_tuned(Solver *s) {
     const int ablate = (g_ablate & 255) | (xcd_run_log() << 8);
     float *out0 = (float *)(g_out0 ? g_out0 : s->b.density), *out1 = (float *)(g_out1 ? g_out1 : s->b.pressure);
     float2 *pd_out = g_out0 ? nullptr : (float2 *)s->b.pd;  // not in timing experiments
-    if (s->variant == 2)
+    if (s->variant >= 2)
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, true>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                            (const float *)s->b.restDensity[c], s->b.cellStart, s->b.sortedHash, out0, out1, pd_out,
@@ -539,7 +466,7 @@ int launch_density_tuned(Solver *s) {
     FSA_HIP(hipGetLastError());
     if (pd_out) {
         s->pd_valid = true;
-        s->pd_fast = s->variant == 2;
+        s->pd_fast = s->variant >= 2;
     }
     return FSA_OK;
 }
@@ -547,7 +474,7 @@ int launch_density_tuned(Solver *s) {
 int launch_force_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
     const int c = s->cur;
-    const bool fast = s->variant == 2;
+    const bool fast = s->variant >= 2;
     if (!(s->pd_valid && s->pd_fast == fast)) {
         ScopedTimer t(s, "force_prep");
         const dim3 g((s->n + kBlock - 1) / kBlock), b(kBlock);
@@ -560,6 +487,7 @@ int launch_force_tuned(Solver *s) {
                                (const float4 *)s->b.velMass[c], (const float *)s->b.density,
                                (const float *)s->b.pressure, (float2 *)s->b.pd);
     }
+    if (s->variant == 3 && !g_out0) return launch_force_fast(s);
     ScopedTimer t(s, g_out0 ? "force_dbg" : "force");
     const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;

@@ -49,6 +49,20 @@ constexpr int kRowTableStride = 20;
 constexpr int kListSlots = 64;
 constexpr int kListOverflow = 0xffff;
 
+// Recorded hits of the WCSPH passes (fsa_sph_fast.hip).  A word = {32-candidate bit mask (first candidate
+// highest), segment << kHitSegShift | first candidate's index in the segment's tile}.  Per particle kHitSlots
+// words, stored per block of kTunedBS particles as [slot][lane]: slot s < kMaxSegs holds the first word of
+// segment s (always written for the segments the block has), the slots from kMaxSegs on hold, in neighbour order,
+// what did not fit there (a lane's range of more than 32 candidates; TYPE_BOUNDARY neighbours, flagged
+// kHitWallFlag).  hitCount = number of those extra words, kHitOverflow for a particle without a record, which
+// walks the cells instead.
+constexpr int kMaxSegs = 18;  // a block's nine rows, the long ones as two tiles each (see Segments below)
+constexpr int kHitExtra = 6;
+constexpr int kHitSlots = kMaxSegs + kHitExtra;
+constexpr int kHitOverflow = 255;
+constexpr unsigned kHitWallFlag = 0x80000000u;
+constexpr int kHitSegShift = 16;
+
 __device__ __forceinline__ void block_row(const DevParams<float> &P, unsigned hlo, unsigned hhi, bool grid_ok, int r,
                                           const int *__restrict__ cellStart, int &s, int &len) {
     s = 0;
@@ -169,7 +183,6 @@ __device__ __forceinline__ void row_store(Shared &sh, int buf, const float4 (&e)
 
 // Segments (WCSPH density and force kernels): a row longer than a tile is walked as two tiles.  A block of class 1
 // has its nine rows as nine segments; a block of class 2 (rows up to kRowCapBig, see above) up to 18.
-constexpr int kMaxSegs = 18;
 struct Segments {
     int start[kMaxSegs];  // first particle (global index)
     int len[kMaxSegs];

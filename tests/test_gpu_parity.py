@@ -68,7 +68,7 @@ SCENES = {
 }
 
 
-VARIANTS = {"generic": 0, "tuned": 1, "fast": 2}
+VARIANTS = {"generic": 0, "tuned": 1, "fast": 2, "fast3": 3}
 
 
 @pytest.fixture(params=[(sc, v) for sc in sorted(SCENES) for v in sorted(VARIANTS)],
@@ -79,7 +79,7 @@ def pair(request, orc32):
     p_o, st = oracle_pair(orc32, sc)
     p_g, s = gpu_solver(sc)
     s.set_variant(VARIANTS[variant])
-    s.exact_arithmetic = variant != "fast"
+    s.exact_arithmetic = not variant.startswith("fast")
     yield sc, p_o, st, p_g, s
     s.close()
     st.close()
