@@ -220,7 +220,7 @@ BUFFERS = {
     "type": ("i", 1), "group": ("i", 1), "uniqueId": ("i", 1), "indexTable": ("i", 1),
     "particleHash": ("i", 1), "particleIndex": ("i", 1),
     "gridCellStart": ("c", 0), "gridCellEnd": ("c", 0), "cellStartDense": ("c", 1),
-    "orderKey": ("l", 1), "neighbourCount": ("i", 1),
+    "orderKey": ("l", 1), "neighbourCount": ("i", 1), "hitCount": ("i", 1),
     "DF_factor": ("r", 1), "pstiff": ("r", 1), "error": ("r", 1),
     "dii": ("r", 3), "dijpjl": ("r", 3), "pressureForce": ("r", 3), "aii": ("r", 1), "density_star": ("r", 1),
 }

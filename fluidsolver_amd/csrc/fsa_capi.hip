@@ -651,6 +651,16 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
         for (size_t i = 0; i < N; i++) out[i] = h[i] == 0xffff ? -1 : (int)h[i];
         return FSA_OK;
     }
+    if (k == "hitCount") {  // extra words of each particle's recorded hits of the last variant-3 pass; -1 = walks the cells
+        TRY(want(N * sizeof(int)));
+        if (!s->hits_valid) return fail(FSA_ERR_INVALID, "hitCount needs the record of a variant-3 density or force pass");
+        std::vector<unsigned char> h(N);
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        if (N) FSA_HIP(hipMemcpy(h.data(), s->b.hitCount, N, hipMemcpyDeviceToHost));
+        int *out = (int *)dst;
+        for (size_t i = 0; i < N; i++) out[i] = h[i] == 255 ? -1 : (int)h[i];
+        return FSA_OK;
+    }
     if (k == "force") { TRY(want(N * 3 * R)); return copy_out(s, s->b.force, dst, bytes); }
     if (k == "v_star") { TRY(want(N * 3 * R)); return copy_out(s, s->b.v_star, dst, bytes); }
     if (k == "density") { TRY(want(N * R)); return copy_out(s, s->b.density, dst, bytes); }

@@ -25,6 +25,37 @@ __device__ __forceinline__ void force_pair_fast(ForceSelf<float> &S, float sr, f
     S.fz = __builtin_fmaf(S.v.z - vj.z, vc, S.fz);
 }
 
+// One TYPE_BOUNDARY neighbour of a fluid particle in the fast flavour (the penalty force and the wall viscosity of
+// ForceCell, solver/sph_kernel_impl.cuh:315-352, which have no range test: every wall particle of the 27 cells
+// counts): fp32 throughout, reciprocal square root and reciprocal instead of the divisions.  Fluid in contact with
+// a wall has dozens of such neighbours per particle, so their cost decides the force pass of a developed flow.
+struct WallConsts {
+    float inv_sr, kb, visc;
+    __device__ __forceinline__ explicit WallConsts(const DevParams<float> &P)
+        : inv_sr(1.0f / P.sr), kb((float)(0.02 * 88.5 * 88.5)), visc((float)((double)(2 * P.boundary_visc * P.sr) * 88.5 / 2000)) {}
+};
+__device__ __forceinline__ void wall_pair_fast(ForceSelf<float> &Sb, const WallConsts &W, float sr, float kspiky,
+                                               float visc_eps, float xx, float xy, float xz, float d2, bool ok,
+                                               float mass_j, float vjx, float vjy, float vjz) {
+    const float rinv = __builtin_amdgcn_rsqf(d2);
+    const float d = d2 * rinv;
+    const float q = d * W.inv_sr;
+    const float t2 = 2.0f - q;
+    float B = q < 0.66666f ? 0.66666f : (q < 1.0f ? q * __builtin_fmaf(-1.5f, q, 2.0f) : 0.5f * t2 * t2);
+    B = q < 2.0f ? B * W.kb * rinv : 0.0f;
+    const float mag = ok ? mass_j * __builtin_amdgcn_rcpf(Sb.v.w + mass_j) * B : 0.0f;
+    const float vx = Sb.v.x - vjx, vy = Sb.v.y - vjy, vz = Sb.v.z - vjz;
+    const float xv = __builtin_fmaf(vz, xz, __builtin_fmaf(vy, xy, vx * xx));
+    const float c = sr - d;
+    const float nablaw = kspiky * c * c * rinv;
+    const float pi_ = -W.visc * xv * __builtin_amdgcn_rcpf(d2 + visc_eps);
+    const float tv = (ok && xv < 0.0f) ? pi_ * nablaw * mass_j : 0.0f;
+    const float k = mag - tv;
+    Sb.fx = __builtin_fmaf(xx, k, Sb.fx);
+    Sb.fy = __builtin_fmaf(xy, k, Sb.fy);
+    Sb.fz = __builtin_fmaf(xz, k, Sb.fz);
+}
+
 // Per-particle walks in the fast flavour, for blocks that cannot use the row tiles.  They evaluate the
 // same expressions in the same order as the tiled kernels, so a particle's result does not depend on
 // which path its block took (nor, in a slab run, on how the particles are split over solvers).
@@ -51,7 +82,7 @@ __device__ __forceinline__ float density_walk_global_fast(const DevParams<float>
     return dens;
 }
 
-// S collects the fluid neighbours, Sb the TYPE_BOUNDARY ones (exact arithmetic, summed separately).
+// S collects the fluid neighbours, Sb the TYPE_BOUNDARY ones (summed separately).
 __device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P, int index, ForceSelf<float> &S,
                                                        ForceSelf<float> &Sb, const float4 *__restrict__ posType,
                                                        const float4 *__restrict__ velMass,
@@ -59,6 +90,7 @@ __device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P
                                                        const int *__restrict__ cellStart) {
     const float sr = P.sr, sr2 = sr * sr;
     const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+    const WallConsts W(P);
     const RowWalk<float> walk(P, S.p.x, S.p.y, S.p.z);
     for (int dz = -1; dz <= 1; dz++)
         for (int dy = -1; dy <= 1; dy++) {
@@ -72,10 +104,10 @@ __device__ __forceinline__ void force_walk_global_fast(const DevParams<float> &P
                     const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
                     if (d2 < sr2 && j != index)
                         force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, true, velMass[j], pd[j]);
-                } else {
-                    const float d2 = xx * xx + xy * xy + xz * xz;
-                    if (force_pair_active(tj, j == index, d2, sr2))
-                        force_pair(P, sr, sr2, Sb, j == index, pj, velMass[j], pd[j].x, 1.0f);
+                } else if (tj == FSA_TYPE_BOUNDARY) {
+                    const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                    const float4 vj = velMass[j];
+                    wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, true, vj.w, vj.x, vj.y, vj.z);
                 }
             }
         }

@@ -110,7 +110,8 @@ struct Solver {
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
-    int variant = 2;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32
+    int variant = 3;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32,
+                      // 3 as 2 with one neighbour search per step (fsa_sph_fast.hip; same bits as 2)
     // timing
     bool timing = false;
     std::vector<std::string> kernel_names;

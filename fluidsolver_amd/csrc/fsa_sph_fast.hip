@@ -185,18 +185,18 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
             // far-away padding until the others are done, and the last (partial) groups come in one trip of
             // their own at the end.
             //
-            // Record: four hit bits per trip are shifted into c2:c1:c0 in every lane (96 bits: nothing is
-            // written inside the cull -- a store issued there would make the wait for the next tile a wait for
-            // the store as well), so bit k from the top belongs to candidate 4 * (lj >> 2) + k; the bits of the
-            // last partial group are kept apart and put in their place afterwards.
-            unsigned c0 = 0, c1 = 0, c2 = 0, hl = 0;
+            // Record: one bit per candidate is shifted into `m` (an add with carry), and every eight trips -- the
+            // same trips in every lane -- the full word moves to c2, c1, c0 in turn (96 bits: nothing is written
+            // inside the cull -- a store issued there would make the wait for the next tile a wait for the store
+            // as well), so bit k from the top belongs to candidate 4 * (lj >> 2) + k; the bits of the last partial
+            // group are kept apart and put in their place afterwards.
+            unsigned c0 = 0, c1 = 0, c2 = 0, m = 0, hl = 0;
             int trips = 0;  // the same in every lane
-            auto cull_group = [&](bool go, int g, int lo, int hi, auto masked_tag) -> unsigned {
+            auto cull_group = [&](bool go, int g, int lo, int hi, unsigned &bits, auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
                 const int gg = go ? g : Shared::kPad;
                 float d2[kChunk];
                 group_d2<true>(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], pi.x, pi.y, pi.z, d2);
-                unsigned h4 = 0;
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
                     const unsigned hit = (d2[u] < sr2 && (!MASKED || (u >= lo && u < hi))) ? 1u : 0u;
@@ -204,32 +204,36 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
                         q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
                         cnt += (int)hit;
                     }
-                    h4 = h4 + h4 + hit;
+                    bits = bits + bits + hit;
                 }
-                return h4;
             };
-            auto shift_in = [&](unsigned h4) {
-                c2 = __funnelshift_l(c1, c2, 4);
-                c1 = __funnelshift_l(c0, c1, 4);
-                c0 = (c0 << 4) | h4;
+            auto trip_done = [&]() {
                 trips++;
+                if ((trips & 7) == 0) {
+                    c2 = trips == 8 ? m : c2;
+                    c1 = trips == 16 ? m : c1;
+                    c0 = trips == 24 ? m : c0;
+                    m = 0;
+                }
             };
             const bool has = lj < le;
             const int g0 = lj >> 2;
             int base = lj & ~(kChunk - 1);
             if (wave_any(has)) {  // first group
-                shift_in(cull_group(has, g0, lj - base, le - base, std::true_type()));
+                cull_group(has, g0, lj - base, le - base, m, std::true_type());
+                trip_done();
                 if (EVAL && wave_any(cnt > Q - kChunk)) drain();
             }
             base = has ? base + kChunk : le;
             while (wave_any(base + kChunk <= le)) {  // whole groups
                 const bool go = base + kChunk <= le;
-                shift_in(cull_group(go, base >> 2, 0, kChunk, std::false_type()));
+                cull_group(go, base >> 2, 0, kChunk, m, std::false_type());
+                trip_done();
                 base += go ? kChunk : 0;
                 if (EVAL && wave_any(cnt > Q - kChunk)) drain();
             }
             if (wave_any(base < le)) {  // last group
-                hl = cull_group(base < le, base >> 2, 0, le - base, std::true_type());
+                cull_group(base < le, base >> 2, 0, le - base, hl, std::true_type());
                 if (EVAL && wave_any(cnt > Q - kChunk)) drain();
             }
             const bool walls_here = wallSeg[r] != 0;
@@ -240,20 +244,14 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
                 if (wall) wallSeg[r + 1] = 1;
             }
             {
-                // left-align the 4 * trips bits in the 96 (first candidate at bit 31 of c2): trips <= 24 here, a
-                // segment of more groups per lane has lost its oldest bits and the lane gives up its record
-                const int sft = 96 - 4 * min(trips, 24), ws = sft >> 5, t = sft & 31;
-                if (ws >= 2) {
-                    c2 = c0;
-                    c1 = c0 = 0;
-                } else if (ws == 1) {
-                    c2 = c1;
-                    c1 = c0;
-                    c0 = 0;
+                // the started word, left-aligned; a segment of more than 24 groups per lane has lost bits and the
+                // lane gives up its record
+                if (trips & 7) {
+                    m <<= 32 - 4 * (trips & 7);
+                    c2 = trips < 8 ? m : c2;
+                    c1 = (trips > 8 && trips < 16) ? m : c1;
+                    c0 = (trips > 16 && trips < 24) ? m : c0;
                 }
-                c2 = __funnelshift_l(c1, c2, t);
-                c1 = __funnelshift_l(c0, c1, t);
-                c0 <<= t;
                 // the last partial group, (base >> 2) - g0 groups from the start
                 const int off = 4 * ((base >> 2) - g0);
                 const unsigned hv = off < 96 ? hl << (28 - (off & 31)) : 0u;
@@ -261,11 +259,23 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
                 c1 |= (off >= 32 && off < 64) ? hv : 0u;
                 c0 |= off >= 64 ? hv : 0u;
                 const unsigned meta = ((unsigned)r << kHitSegShift) | (unsigned)(4 * g0);
-                // the segment's first word has a slot of its own, so that the force pass can fetch it ahead
-                if (!(dbg & 1)) out[(size_t)r * BS] = make_uint2(c2, meta);
-                put_word(c1, meta + 32);
-                put_word(c0, meta + 64);
-                if (trips > 24 || (hl && off >= 96)) words = kHitSlots + 1;  // no record for this particle
+                // the particle itself counts in the density sum but not in the force sum: its bit is dropped
+                if (sg.row[r] == 4) {
+                    const int own = index - sg.start[r], o = own - 4 * g0;
+                    if (active && own >= 0 && own < sg.len[r] && o >= 0 && o < 96) {
+                        const unsigned bit = ~(0x80000000u >> (o & 31));
+                        c2 &= o < 32 ? bit : ~0u;
+                        c1 &= (o >= 32 && o < 64) ? bit : ~0u;
+                        c0 &= o >= 64 ? bit : ~0u;
+                    }
+                }
+                // the segment's main word: candidates 0..56 from the group g0 on, g0 itself in the low seven bits
+                static_assert((ROWCAP + kChunk) / kChunk < (1 << kHitMainShift), "group index does not fit");
+                if (!(dbg & 1)) out[(size_t)r * BS] = make_uint2(c2, (c1 & ~kHitMainMask) | (unsigned)g0);
+                // what lies beyond (ranges of more than 57 candidates: rare) goes to the extra words
+                put_word((c1 << (32 - kHitMainShift)) | (c0 >> kHitMainShift), meta + 64 - kHitMainShift);
+                put_word(c0 << (32 - kHitMainShift), meta + 96 - kHitMainShift);
+                if (trips > 24 || (hl && off >= 96)) words = kHitExtra + 1;  // no record for this particle
             }
             // TYPE_BOUNDARY neighbours count for fluid particles wherever they are in the 27 cells (ForceCell has
             // no range test on that branch): words of their own, flagged, after the segment's fluid words
@@ -308,11 +318,18 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
 // force: replay of the recorded hits from full-data row tiles
 // ------------------------------------------------------------------------------------------------
 template <int ROWCAP> struct PairTile {
-    float4 A[2][ROWCAP];  // x, y, z, mass
-    float4 B[2][ROWCAP];  // velocity, pressure / density^2
-    float C[2][ROWCAP];   // mass / density * 2 * viscosity
+    float4 A[2 * ROWCAP];  // x, y, z, mass          (two tiles: segment s lives in tile s & 1)
+    float4 B[2 * ROWCAP];  // velocity, pressure / density^2
+    float C[2 * ROWCAP];   // mass / density * 2 * viscosity
 };
 
+// A lane works through its segments in order.  During segment r the tiles of segments r - 1 and r are both in LDS,
+// so a lane may still be busy with segment r - 1 while others are ahead.  The loop of segment r runs in two parts:
+// the first ends when no lane of the wavefront has bits of segment r - 1 left, then (workgroup barrier) the tile of
+// segment r + 1 takes the place of that of r - 1, and the second part goes on with segment r until fewer than
+// `quorum` lanes have bits left -- those carry them over into the next segment's loop.  That keeps most lanes
+// busy in every trip although a lane's hits per row vary a lot (on a lattice half the lanes have no neighbour at
+// all in a given row).
 template <int BS, int ROWCAP>
 __global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int n,
                                                         const float4 *__restrict__ posType,
@@ -330,6 +347,7 @@ __global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int 
     const int tid = threadIdx.x;
     const int dbg = run_log >> 8;
     run_log &= 255;
+    const int quorum = (dbg >> 4) ? (dbg >> 4) : 40;
     const int blk = xcd_block(run_log);
     const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
@@ -362,19 +380,26 @@ __global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int 
         S.v = velMass[index];
         S.pterm = pd[index].x;
         cnt = hitCount[index];
-        rec = cnt != kHitOverflow && !(dbg & 4);
+        if (dbg & 4) cnt = kHitOverflow;
+        rec = cnt != kHitOverflow;
     }
-    // wall neighbours are summed on their own (the reference's arithmetic) and added at the end
+    // wall neighbours are summed on their own and added at the end
     ForceSelf<float> Sb = S;
     const float sr = P.sr, sr2 = sr * sr;
     const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
-    if (cnt == kHitOverflow) force_walk_global_fast(P, index, S, Sb, posType, velMass, pd, cellStart);
+    const WallConsts W(P);
+    if (cnt == kHitOverflow && !(dbg & 8)) force_walk_global_fast(P, index, S, Sb, posType, velMass, pd, cellStart);
     if (!rec) cnt = 0;
     if (staged) {
         const uint2 *const wp = hitWords + (size_t)blk * kHitSlots * BS + tid;
-        int w = 0;  // extra words taken so far
-        uint2 nxt = cnt > 0 ? wp[(size_t)kMaxSegs * BS] : make_uint2(0u, 0u);
-        uint2 fw = wp[0];  // the first word of the segment at hand (a slot per segment: fetched a segment ahead)
+        constexpr unsigned kNoSeg = 0x7fffu;
+        auto extra_at = [&](int k) { return k < cnt ? wp[(size_t)(kMaxSegs + k) * BS] : make_uint2(0u, kNoSeg << kHitSegShift); };
+        int xk = 0;                 // extra words taken so far
+        uint2 xw = extra_at(0);     // the next one
+        unsigned cur = 0, pend = 0; // bits at hand (32 candidates from `cbase` on), and the 25 after them
+        int cseg = -1;              // the segment they belong to
+        int cbase = 0;              // tile entry of bit 31 of `cur`, the two tiles counted through
+        bool cwall = false;         // they are TYPE_BOUNDARY particles
         struct Stage {
             float4 p, v;
             float2 a;
@@ -394,83 +419,111 @@ __global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int 
             for (int k = 0; k < row_regs<BS, ROWCAP - kChunk>(); k++) {
                 const int i = tid + k * BS;
                 if (i < len) {
-                    tile.A[buf][i] = make_float4(e[k].p.x, e[k].p.y, e[k].p.z, e[k].v.w);
-                    tile.B[buf][i] = make_float4(e[k].v.x, e[k].v.y, e[k].v.z, e[k].a.x);
-                    tile.C[buf][i] = e[k].a.y;
+                    tile.A[buf * ROWCAP + i] = make_float4(e[k].p.x, e[k].p.y, e[k].p.z, e[k].v.w);
+                    tile.B[buf * ROWCAP + i] = make_float4(e[k].v.x, e[k].v.y, e[k].v.z, e[k].a.x);
+                    tile.C[buf * ROWCAP + i] = e[k].a.y;
                 }
             }
         };
         Stage e[row_regs<BS, ROWCAP - kChunk>()];
+        if (tid < 2) {  // entry 0 of both tiles is what a lane without a neighbour reads: never uninitialised
+            tile.A[tid * ROWCAP] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tile.B[tid * ROWCAP] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tile.C[tid * ROWCAP] = 0.f;
+        }
+        __syncthreads();
         const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
         fetch(sh.rowStartG[0], len0, e);
+        uint2 fw = rec ? wp[0] : make_uint2(0u, 0u);  // main word of the segment whose loop runs
         store(0, len0, e);
         __syncthreads();
         const int nseg = sg.count;
+        if (nseg > 1) fetch(sg.start[1], sg.len[1], e);
         for (int r = 0; r < nseg; r++) {
-            const int buf = r & 1;
-            const int seg_start = sg.start[r];
-            int nlen = 0;
             uint2 fwn = make_uint2(0u, 0u);
-            if (r + 1 < nseg) {  // in flight during the replay below
-                nlen = sg.len[r + 1];
-                if (!(dbg & 2)) fetch(sg.start[r + 1], nlen, e);
-                fwn = wp[(size_t)(r + 1) * BS];
-            }
-            // the lane's words of this segment, in order; `cur` only ever holds bits of the segment at hand
-            unsigned cur = rec ? fw.x : 0u;
-            int base = (int)(fw.y & ((1u << kHitSegShift) - 1u));  // candidate at bit 31, as an index into the tile
-            bool wallw = false;
+            if (r + 1 < nseg && rec) fwn = wp[(size_t)(r + 1) * BS];  // in flight during this segment's loop
             struct Nb {
                 bool has, wall;
-                int j;
+                int t;
                 float4 a, b;
                 float c;
             };
-            auto next = [&](Nb &N) {
-                if (cur == 0 && w < cnt && (int)((nxt.y & ~kHitWallFlag) >> kHitSegShift) == r) {
-                    cur = nxt.x;
-                    base = (int)(nxt.y & ((1u << kHitSegShift) - 1u));
-                    wallw = (nxt.y & kHitWallFlag) != 0;
-                    w++;
-                    if (w < cnt) nxt = wp[(size_t)(kMaxSegs + w) * BS];  // in flight until the word is used up
+            // Moves the lane on to its next bits when those at hand are used up.
+            auto refill = [&]() {
+                if (wave_any(cur == 0)) {
+                    if (cur == 0) {
+                        if (pend != 0) {
+                            cur = pend;
+                            pend = 0;
+                            cbase += 32;
+                        } else if (((xw.y & ~kHitWallFlag) >> kHitSegShift) == (unsigned)cseg) {  // an extra word of this segment
+                            cur = xw.x;
+                            cwall = (xw.y & kHitWallFlag) != 0;
+                            cbase = (cseg & 1) * ROWCAP + (int)(xw.y & ((1u << kHitSegShift) - 1u));
+                            xw = extra_at(++xk);
+                        } else if (cseg < r) {  // on to segment r, whose main word is `fw`
+                            cseg = r;
+                            cwall = false;
+                            cur = fw.x;
+                            pend = fw.y & ~kHitMainMask;
+                            cbase = (r & 1) * ROWCAP + 4 * (int)(fw.y & kHitMainMask);
+                        }
+                    }
                 }
-                N.has = cur != 0;
+            };
+            // Takes the lane's next neighbour and starts the tile reads.  `part` 0: until every lane has reached
+            // segment r; 1: until fewer than `quorum` lanes have bits left (all of them in the last segment).
+            auto next = [&](Nb &N, int part) -> bool {
+                refill();
+                const bool has = cur != 0;
+                if (part == 0) {
+                    if (!wave_any(cseg < r)) return false;  // a lane moves on to r when it is through with r - 1
+                } else {
+                    const unsigned long long busy = __ballot(has);
+                    if (busy == 0ull || (r + 1 < nseg && __popcll(busy) < quorum)) return false;
+                }
+                N.has = has;
+                N.wall = has && cwall;
                 const int k = __builtin_clz(cur | 1u);  // cur == 0: nothing to clear
                 cur &= ~(0x80000000u >> k);
-                const int t = N.has ? base + k : 0;
-                N.j = seg_start + t;
-                N.wall = N.has && wallw;
-                N.a = tile.A[buf][t];
-                N.b = tile.B[buf][t];
-                N.c = tile.C[buf][t];
+                N.t = has ? cbase + k : 0;
+                N.a = tile.A[N.t];
+                N.b = tile.B[N.t];
+                N.c = tile.C[N.t];
+                return true;
             };
             auto eval = [&](const Nb &N) {
                 if (dbg & 1) { S.fx += N.a.x + N.b.x + N.c; return; }
                 const float xx = S.p.x - N.a.x, xy = S.p.y - N.a.y, xz = S.p.z - N.a.z;
                 const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                // straight-line: an entry that does not count is evaluated anyway and zeroed by selects
-                const bool ok = N.has && !N.wall && d2 < sr2 && N.j != index;
-                force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, ok, make_float4(N.b.x, N.b.y, N.b.z, N.a.w),
-                                make_float2(N.b.w, N.c));
-                if (wave_any(N.wall)) {  // wall particles (rare): from global memory, the reference's arithmetic
-                    if (N.wall) force_pair(P, sr, sr2, Sb, false, posType[N.j], velMass[N.j], pd[N.j].x, 1.0f);
+                // straight-line: a lane without a neighbour in this trip evaluates entry 0 and adds exact zeros
+                force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, N.has && !N.wall,
+                                make_float4(N.b.x, N.b.y, N.b.z, N.a.w), make_float2(N.b.w, N.c));
+                if (wave_any(N.wall))  // wall particles: summed apart
+                    wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, N.wall, N.a.w, N.b.x, N.b.y, N.b.z);
+            };
+            // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated
+            auto run = [&](int part) {
+                Nb N0, N1;
+                bool go = next(N0, part);
+                while (go) {
+                    const bool go1 = next(N1, part);
+                    eval(N0);
+                    if (!go1) break;
+                    go = next(N0, part);
+                    eval(N1);
                 }
             };
-            // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated.
-            // A lane that has run out of bits for this segment stays out until the next one.
-            Nb N0, N1;
-            next(N0);
-            while (wave_any(N0.has)) {
-                next(N1);
-                eval(N0);
-                if (!wave_any(N1.has)) break;
-                next(N0);
-                eval(N1);
-            }
+            run(0);
             if (r + 1 < nseg) {
-                store(buf ^ 1, nlen, e);
+                __syncthreads();  // everyone is done with the tile of segment r - 1
+                store((r + 1) & 1, sg.len[r + 1], e);
+                if (r + 2 < nseg && !(dbg & 2)) fetch(sg.start[r + 2], sg.len[r + 2], e);
+            }
+            run(1);
+            if (r + 1 < nseg) {
                 fw = fwn;
-                __syncthreads();  // segment r + 1 visible; everyone is done with the buffer of segment r - 1
+                __syncthreads();  // the tile of segment r + 1 is visible
             }
         }
     }
@@ -489,7 +542,7 @@ __global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int fast_dbg() { const char *e = getenv("FSA_FAST_DBG"); return e ? atoi(e) : 0; }
+static int fast_dbg() { const char *e = getenv("FSA_FAST_DBG"); return e ? atoi(e) : 0; }  // experiments
 constexpr int kQueueD = 10;  // density queue: 4-byte slots (with the tile: 19.6 KB of LDS per workgroup)
 
 static inline int tiled_grid(const Solver *s, int run_log) {

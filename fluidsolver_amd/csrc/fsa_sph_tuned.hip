@@ -270,6 +270,7 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
         }
     } else {
         const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+        const WallConsts W(P);
         const float sr2c = FAST ? sr2 : sr2 * 1.000002f;  // the unfused test of EXACT comes later
         const RowWalk<float> walk(P, S.p.x, S.p.y, S.p.z);
         unsigned short *const q = queue + tid;
@@ -316,11 +317,15 @@ __global__ __launch_bounds__(BS) void force_tuned_kernel(DevParams<float> P, int
                     other |= tj != FSA_TYPE_FLUID && s + u < cnt;
                     force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, ok, B.vj[u], B.aj[u]);
                 }
-                if (wave_any(other)) {  // wall particles among them (rare)
+                if (wave_any(other)) {  // wall particles among them: summed apart, see wall_pair_fast
 #pragma unroll
-                    for (int u = 0; u < kDrainBatch; u++)
-                        if (s + u < cnt && unpack_int(B.pj[u].w) != FSA_TYPE_FLUID)
-                            evaluate_exact(B.j[u], B.pj[u], B.vj[u], B.aj[u]);
+                    for (int u = 0; u < kDrainBatch; u++) {
+                        const float xx = S.p.x - B.pj[u].x, xy = S.p.y - B.pj[u].y, xz = S.p.z - B.pj[u].z;
+                        const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                        const bool wl = s + u < cnt && unpack_int(B.pj[u].w) == FSA_TYPE_BOUNDARY;
+                        wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, wl, B.vj[u].w, B.vj[u].x, B.vj[u].y,
+                                       B.vj[u].z);
+                    }
                 }
             } else {
 #pragma unroll
@@ -487,7 +492,8 @@ int launch_force_tuned(Solver *s) {
                                (const float4 *)s->b.velMass[c], (const float *)s->b.density,
                                (const float *)s->b.pressure, (float2 *)s->b.pd);
     }
-    if (s->variant == 3 && !g_out0) return launch_force_fast(s);
+    // scenes with TYPE_RIGID particles run another density kernel, which records nothing: they keep the search
+    if (s->variant == 3 && !g_out0 && !s->has_rigid) return launch_force_fast(s);
     ScopedTimer t(s, g_out0 ? "force_dbg" : "force");
     const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;

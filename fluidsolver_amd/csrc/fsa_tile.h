@@ -49,16 +49,21 @@ constexpr int kRowTableStride = 20;
 constexpr int kListSlots = 64;
 constexpr int kListOverflow = 0xffff;
 
-// Recorded hits of the WCSPH passes (fsa_sph_fast.hip).  A word = {32-candidate bit mask (first candidate
-// highest), segment << kHitSegShift | first candidate's index in the segment's tile}.  Per particle kHitSlots
-// words, stored per block of kTunedBS particles as [slot][lane]: slot s < kMaxSegs holds the first word of
-// segment s (always written for the segments the block has), the slots from kMaxSegs on hold, in neighbour order,
-// what did not fit there (a lane's range of more than 32 candidates; TYPE_BOUNDARY neighbours, flagged
-// kHitWallFlag).  hitCount = number of those extra words, kHitOverflow for a particle without a record, which
-// walks the cells instead.
+// Recorded hits of the WCSPH passes (fsa_sph_fast.hip), per block of kTunedBS particles as [slot][lane] (a
+// wavefront reads and writes 512 contiguous bytes per slot), kHitSlots 8-byte slots per particle:
+//   slot s < kMaxSegs : the main word of segment s, written for every segment the block has: a bit mask of the 57
+//                       candidates from group g0 of the segment's tile on (first candidate at bit 31 of .x, the 33rd at
+//                       bit 31 of .y) and g0 in the low kHitMainShift bits of .y;
+//   the slots after   : extra words in neighbour order, {32-candidate mask (first candidate highest), flags |
+//                       segment << kHitSegShift | first candidate's index in the tile}: what a lane's range holds
+//                       beyond 57 candidates, and TYPE_BOUNDARY neighbours (flagged kHitWallFlag), which count
+//                       wherever they are in the 27 cells.
+// hitCount = number of extra words, kHitOverflow for a particle without a record, which walks the cells instead.
 constexpr int kMaxSegs = 18;  // a block's nine rows, the long ones as two tiles each (see Segments below)
-constexpr int kHitExtra = 6;
+constexpr int kHitExtra = 14;
 constexpr int kHitSlots = kMaxSegs + kHitExtra;
+constexpr int kHitMainShift = 7;
+constexpr unsigned kHitMainMask = (1u << kHitMainShift) - 1u;
 constexpr int kHitOverflow = 255;
 constexpr unsigned kHitWallFlag = 0x80000000u;
 constexpr int kHitSegShift = 16;

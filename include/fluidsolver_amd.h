@@ -305,12 +305,17 @@ int fsa_timing_read(fsa_solver *s, fsa_kernel_time *out, int cap, int *count);
  *      operation for operation as the reference's expressions;
  *   1  tuned structure (LDS row tiles + per-lane hit queues), same exact arithmetic;
  *   2  tuned structure, fast fp32 arithmetic (hardware sqrt/rsq/rcp, fused multiply-adds): about
- *      1e-7 relative away from variant 1 per neighbour term.  Default.  The IISPH passes (all but the
- *      non-pressure force) and the three kernels of the DFSPH correction loops have such a flavour too; the
- *      remaining DFSPH and IISPH passes run the exact arithmetic in every variant. */
+ *      1e-7 relative away from variant 1 per neighbour term; TYPE_BOUNDARY neighbours of the force pass in
+ *      fp32 with reciprocals as well.  The IISPH passes (all but the non-pressure force) and the three kernels
+ *      of the DFSPH correction loops have such a flavour too; the remaining DFSPH and IISPH passes run the
+ *      exact arithmetic in every variant;
+ *   3  as 2, but the WCSPH step searches its neighbours once: the density pass also records one bit per
+ *      candidate and the force pass replays the set bits from row tiles that hold everything a pair needs.
+ *      Same arithmetic in the same order: bit for bit the results of variant 2.  Default.  Uses 256 bytes of
+ *      device memory per particle of the solver's capacity (allocated by fsa_create). */
 int fsa_set_variant(fsa_solver *s, int variant);
 
-/* Recorded neighbour lists (fp32, variants 1 and 2; no counterpart in the reference, which walks the 27
+/* Recorded neighbour lists (fp32, variants 1 to 3; no counterpart in the reference, which walks the 27
  * cells in every kernel).  The IISPH and DFSPH steps run 20-odd neighbour passes between two sorts over the
  * same positions: with lists enabled (the default) the first such pass after a sort records, per particle
  * and in the reference's neighbour order, every particle within the support radius, and the passes replay

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--backend", choices=["oracle", "hip"], required=True)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--recut-at", type=int, default=0, help="re-cut the slabs after this many steps")
     a = ap.parse_args()
 

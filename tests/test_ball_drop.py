@@ -38,7 +38,7 @@ def test_ball_drop_1000_steps_on_the_oracle(orc32):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 3])
 def test_ball_drop_gpu_follows_oracle(orc32, variant):
     sc = scenes.ball_drop()
     p_o, st = oracle_pair(orc32, sc)

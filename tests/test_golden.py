@@ -51,7 +51,7 @@ def test_oracle_reproduces_golden(precision, orc32, orc64):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,variant", [("f32", 0), ("f32", 1), ("f32", 2), ("f64", 0)])
+@pytest.mark.parametrize("precision,variant", [("f32", 0), ("f32", 1), ("f32", 2), ("f32", 3), ("f64", 0)])
 def test_hip_matches_golden(precision, variant):
     from fluidsolver_amd import capi
     g, sc = load(precision)

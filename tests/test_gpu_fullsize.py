@@ -57,14 +57,16 @@ def test_tuned_kernels_agree_with_generic_full_size(big):
     sc, p, s = big
     s.sort_particles()
     out = {}
-    for v in (0, 2):
+    for v in (0, 2, 3):
         s.set_variant(v)
         s.compute_pressure()
         d = s.get("density")
         s.compute_force()
         out[v] = (d, s.get("force"))
-    s.set_variant(2)
+    s.set_variant(3)
     fluid = s.get("type") == 0
+    # variant 3 replays the hits its density pass recorded: the bits of variant 2
+    assert np.array_equal(out[3][0], out[2][0]) and np.array_equal(out[3][1][fluid], out[2][1][fluid])
     assert rel_err(out[2][0], out[0][0]) <= 1e-5
     assert rel_err(out[2][1][fluid], out[0][1][fluid]) <= 1e-5
     assert np.all(out[2][0][fluid] > 0)  # a fluid particle counts itself; walls only count fluid neighbours

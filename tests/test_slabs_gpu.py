@@ -31,7 +31,7 @@ def plain_gpu_run(sc, steps, variant):
     return res
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 3])
 def test_one_slab_equals_plain_solver(variant):
     """slab mode with a single slab covering the grid: same bits as the ordinary solver"""
     from slab_worker import test_scene
@@ -46,7 +46,7 @@ def test_one_slab_equals_plain_solver(variant):
     ss.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 3])
 def test_two_ranks_equal_plain_solver(tmp_path, orc32, variant):
     from slab_worker import test_scene
     parts = run_ranks(2, "hip", STEPS, tmp_path, variant=variant)

@@ -33,5 +33,8 @@ for v in a.variants:
         res["density_rel_diff"] = float(np.abs(d - ref[0]).max() / np.abs(ref[0]).max())
         fs = np.abs(ref[1][fluid]).max()
         res["force_rel_diff"] = float(np.abs(f[fluid] - ref[1][fluid]).max() / fs)
+    if v == 3:
+        hc = s.get("hitCount")[fluid]
+        res["record"] = {"walks": float((hc < 0).mean()), "extras_mean": float(hc[hc >= 0].mean()), "extras_max": int(hc.max())}
     out[v] = res
     print(v, json.dumps(res), flush=True)
