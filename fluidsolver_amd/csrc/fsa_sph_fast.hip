@@ -36,7 +36,7 @@ namespace fsa {
 // ------------------------------------------------------------------------------------------------
 // EVAL = false: only the record (for a force pass that is not preceded by this solver's density pass).
 template <int BS, int ROWCAP, int Q, bool EVAL>
-__global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, int n,
+__global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> P, int n,
                                                             const float4 *__restrict__ posType,
                                                             const float4 *__restrict__ velMass,
                                                             const float *__restrict__ restDensity,
@@ -199,12 +199,21 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
                 group_d2<true>(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], pi.x, pi.y, pi.z, d2);
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    const unsigned hit = (d2[u] < sr2 && (!MASKED || (u >= lo && u < hi))) ? 1u : 0u;
-                    if (EVAL) {
-                        q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
-                        cnt += (int)hit;
+                    if (EVAL) q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
+                    if constexpr (!MASKED && EVAL) {
+                        // one compare, then the hit goes into the queue count and into the bit mask as a carry
+                        unsigned long long carry_out;
+                        asm("v_cmp_gt_f32 vcc, %[sr2], %[d2]\n\t"
+                            "v_addc_co_u32_e64 %[cnt], %[co], 0, %[cnt], vcc\n\t"
+                            "v_addc_co_u32_e64 %[bits], %[co], %[bits], %[bits], vcc"
+                            : [cnt] "+v"(cnt), [bits] "+v"(bits), [co] "=&s"(carry_out)
+                            : [sr2] "v"(sr2), [d2] "v"(d2[u])
+                            : "vcc");
+                    } else {
+                        const unsigned hit = (d2[u] < sr2 && (!MASKED || (u >= lo && u < hi))) ? 1u : 0u;
+                        if (EVAL) cnt += (int)hit;
+                        bits = bits + bits + hit;
                     }
-                    bits = bits + bits + hit;
                 }
             };
             auto trip_done = [&]() {
@@ -225,11 +234,23 @@ __global__ __launch_bounds__(BS) void density_record_kernel(DevParams<float> P, 
                 if (EVAL && wave_any(cnt > Q - kChunk)) drain();
             }
             base = has ? base + kChunk : le;
-            while (wave_any(base + kChunk <= le)) {  // whole groups
-                const bool go = base + kChunk <= le;
-                cull_group(go, base >> 2, 0, kChunk, m, std::false_type());
-                trip_done();
-                base += go ? kChunk : 0;
+            for (;;) {  // whole groups
+                // the inner loop leaves for everything that is not a plain trip: a full queue, a full word
+                bool more;
+                while ((more = wave_any(base + kChunk <= le))) {
+                    const bool go = base + kChunk <= le;
+                    cull_group(go, base >> 2, 0, kChunk, m, std::false_type());
+                    trips++;
+                    base += go ? kChunk : 0;
+                    if ((trips & 7) == 0 || (EVAL && wave_any(cnt > Q - kChunk))) break;
+                }
+                if (!more) break;
+                if ((trips & 7) == 0) {
+                    c2 = trips == 8 ? m : c2;
+                    c1 = trips == 16 ? m : c1;
+                    c0 = trips == 24 ? m : c0;
+                    m = 0;
+                }
                 if (EVAL && wave_any(cnt > Q - kChunk)) drain();
             }
             if (wave_any(base < le)) {  // last group
@@ -331,7 +352,7 @@ template <int ROWCAP> struct PairTile {
 // busy in every trip although a lane's hits per row vary a lot (on a lattice half the lanes have no neighbour at
 // all in a given row).
 template <int BS, int ROWCAP>
-__global__ __launch_bounds__(BS) void force_rows_kernel(DevParams<float> P, int n,
+__global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, int n,
                                                         const float4 *__restrict__ posType,
                                                         const float4 *__restrict__ velMass,
                                                         const float2 *__restrict__ pd,
