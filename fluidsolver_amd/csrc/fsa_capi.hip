@@ -117,7 +117,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.blockLo, b.blockHi, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -162,7 +162,7 @@ struct Staging {
 };
 
 static void invalidate_order(Solver *s) {
-    s->hash_valid = s->perm_valid = s->sorted_valid = false;
+    s->hash_valid = s->hash_ahead = s->perm_valid = s->sorted_valid = false;
     s->index_table_valid = s->ref_cells_valid = false;
     s->pd_valid = false;
     s->lists_valid = false;
@@ -260,7 +260,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
 
     const size_t N = (size_t)capacity, R = s->real_size(), C = (size_t)s->num_cells;
     const size_t nblocks = (N + kBlock - 1) / kBlock;
-    const size_t scan_tiles = (std::max(C, nblocks) + 1) / (kBlock * 8) + 4;
+    const size_t scan_tiles = (C + 1) / (kBlock * 8) + (nblocks + 1) / (kBlock * 8) + 8;  // both prefix sums at once
     Buffers &b = s->b;
 #define ALLOC(field, bytes, zero) \
     if (rc == FSA_OK) rc = dalloc(field, (bytes), (zero))
@@ -294,6 +294,8 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     ALLOC(b.gridCellEnd, C * sizeof(int), true);
     ALLOC(b.blockRows, (nblocks + 8) * 20 * sizeof(int), true);
     ALLOC(b.bigBlocks, (nblocks + 8) * sizeof(int), true);
+    ALLOC(b.blockLo, (nblocks + 8) * sizeof(int), true);
+    ALLOC(b.blockHi, (nblocks + 8) * sizeof(int), true);
     if (precision == FSA_PRECISION_F32) {  // recorded hits of the WCSPH passes (fsa_sph_fast.hip)
         ALLOC(b.hitWords, (nblocks + 8) * kHitSlots * kTunedBS * 8, false);
         ALLOC(b.hitCount, (nblocks + 8) * kTunedBS, true);
@@ -482,7 +484,8 @@ int fsa_num_undef(fsa_solver *hs, int *n) {
 int fsa_calc_hash(fsa_solver *hs) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    TRY(launch_hash_count(s));
+    if (!s->hash_ahead) TRY(launch_hash_count(s));  // else the last step's integration has done it on the way
+    s->hash_ahead = false;
     s->hash_valid = true;
     s->perm_valid = false;
     s->sorted_valid = false;
@@ -513,7 +516,7 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
     s->pd_valid = false;
     s->lists_valid = false;
     s->hits_valid = false;
-    s->hash_valid = false;  // hash[] described the previous order
+    s->hash_valid = s->hash_ahead = false;  // hash[] described the previous order
     s->perm_valid = false;
     s->index_table_valid = false;
     s->ref_cells_valid = false;
@@ -521,9 +524,22 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
 }
 
 int fsa_sort_particles(fsa_solver *hs) {
-    TRY(fsa_calc_hash(hs));
-    TRY(fsa_sort_particle(hs));
-    return fsa_reorder_data_and_find_cell_start(hs);
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (s->slab) {  // z-slab solvers rank by order key
+        TRY(fsa_calc_hash(hs));
+        TRY(fsa_sort_particle(hs));
+        return fsa_reorder_data_and_find_cell_start(hs);
+    }
+    // the three stages in five launches (see fsa_step); same arrays, same bits
+    if (!s->hash_valid && !s->hash_ahead) TRY(launch_hash_fused(s, false));
+    TRY(launch_sort_fused(s, true));
+    s->cur = 1 - s->cur;
+    s->hash_valid = s->hash_ahead = false;  // hash[] described the previous order
+    s->sorted_valid = s->owned_from_sort = s->count_valid = true;
+    s->pd_valid = s->lists_valid = s->hits_valid = false;
+    s->perm_valid = s->index_table_valid = s->ref_cells_valid = false;
+    return FSA_OK;
 }
 
 int fsa_compute_pressure(fsa_solver *hs) {
@@ -546,7 +562,7 @@ int fsa_advect(fsa_solver *hs) {
     TRY(launch_advect(s));
     // positions moved: the cell ranges no longer describe them
     s->sorted_valid = false;
-    s->hash_valid = false;
+    s->hash_valid = s->hash_ahead = false;
     s->perm_valid = false;
     return FSA_OK;
 }
@@ -562,11 +578,32 @@ int fsa_step(fsa_solver *hs, int nsteps) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
     if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    if (s->slab) {  // z-slab solvers rank by order key: the staged launches
+        for (int k = 0; k < nsteps; k++) {
+            TRY(fsa_sort_particles(hs));
+            TRY(launch_density(s));
+            TRY(launch_force(s));
+            TRY(fsa_advect(hs));
+        }
+        return FSA_OK;
+    }
+    // Seven launches per step: the integration computes the next step's hash and counts on the way, the two
+    // prefix sums share two launches, the rank pass moves the particles and writes the row table.
     for (int k = 0; k < nsteps; k++) {
-        TRY(fsa_sort_particles(hs));
+        if (!s->hash_valid && !s->hash_ahead) TRY(launch_hash_fused(s, false));
+        TRY(launch_sort_fused(s, false));
+        s->hash_valid = s->hash_ahead = false;  // hash[] described the previous order
+        s->cur = 1 - s->cur;
+        s->sorted_valid = true;
+        s->owned_from_sort = true;
+        s->count_valid = true;
+        s->pd_valid = s->lists_valid = s->hits_valid = false;
+        s->perm_valid = s->index_table_valid = s->ref_cells_valid = false;
         TRY(launch_density(s));
         TRY(launch_force(s));
-        TRY(fsa_advect(hs));
+        TRY(launch_hash_fused(s, true));
+        s->sorted_valid = false;  // positions moved: the cell ranges no longer describe them ...
+        s->hash_ahead = true;     // ... but hash / slot / cellCount already do
     }
     return FSA_OK;
 }
@@ -863,7 +900,7 @@ int fsa_update_position(fsa_solver *hs) {
     TRY(launch_update_position(s));
     // positions moved: the cell ranges no longer describe them
     s->sorted_valid = false;
-    s->hash_valid = false;
+    s->hash_valid = s->hash_ahead = false;
     s->perm_valid = false;
     return FSA_OK;
 }
@@ -1024,7 +1061,7 @@ int fsa_iisph_update(fsa_solver *hs) {
     TRY(launch_iisph_integrate(s));
     // positions moved: the cell ranges no longer describe them
     s->sorted_valid = false;
-    s->hash_valid = false;
+    s->hash_valid = s->hash_ahead = false;
     s->perm_valid = false;
     s->pd_valid = false;
     return FSA_OK;

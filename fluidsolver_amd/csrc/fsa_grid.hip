@@ -17,6 +17,7 @@
 #include <mutex>
 #include <utility>
 
+#include "fsa_advect.h"
 #include "fsa_solver.h"
 #include "fsa_tile.h"
 
@@ -25,23 +26,19 @@ namespace fsa {
 // ------------------------------------------------------------------------------------------------
 // 1. hash + count
 // ------------------------------------------------------------------------------------------------
-// PosT: Vec4<T> ({x, y, z, type bits}, the solver's layout) or Vec3<T> (the reference's cfloat3 layout)
-template <typename T, typename PosT>
-__global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, const PosT *__restrict__ posType,
-                                                            int n, int *__restrict__ hash, int *__restrict__ slot,
-                                                            int *__restrict__ cellCount,
-                                                            int *__restrict__ undefBlockCount) {
-    __shared__ int waveCount[kBlock / 64];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i < n;
+// The hash and count of particle i at (x, y, z); every thread of the block calls it (`valid` = there is a particle).
+template <typename T>
+__device__ __forceinline__ void hash_and_count(const DevParams<T> &P, bool valid, int i, T x, T y, T z,
+                                               int *__restrict__ hash, int *__restrict__ slot,
+                                               int *__restrict__ cellCount, int *__restrict__ undefBlockCount,
+                                               int *waveCount /* shared, kBlock / 64 */) {
     unsigned h = 0;
     if (valid) {
-        const PosT p = posType[i];
-        if (!in_domain(P, p.x, p.y, p.z)) {
+        if (!in_domain(P, x, y, z)) {
             h = FSA_GRID_UNDEF;
         } else {
             int cx, cy, cz;
-            calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
+            calc_grid_pos(P, x, y, z, cx, cy, cz);
             h = calc_grid_hash(P, cx, cy, cz);
         }
         hash[i] = (int)h;
@@ -80,6 +77,53 @@ __global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, cons
         for (int w = 0; w < kBlock / 64; w++) tot += waveCount[w];
         undefBlockCount[blockIdx.x] = tot;
     }
+}
+
+// PosT: Vec4<T> ({x, y, z, type bits}, the solver's layout) or Vec3<T> (the reference's cfloat3 layout)
+template <typename T, typename PosT>
+__global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, const PosT *__restrict__ posType,
+                                                            int n, int *__restrict__ hash, int *__restrict__ slot,
+                                                            int *__restrict__ cellCount,
+                                                            int *__restrict__ undefBlockCount) {
+    __shared__ int waveCount[kBlock / 64];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    T x = 0, y = 0, z = 0;
+    if (valid) {
+        const PosT p = posType[i];
+        x = p.x;
+        y = p.y;
+        z = p.z;
+    }
+    hash_and_count(P, valid, i, x, y, z, hash, slot, cellCount, undefBlockCount, waveCount);
+}
+
+// AdvectKernel and the calcHash of the next step in one pass: the new position goes from the integration straight
+// into the hash (cellCount must be all zero on entry).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void advect_hash_kernel(DevParams<T> P, int n, Vec4<T> *__restrict__ posType,
+                                                             Vec4<T> *__restrict__ velMass,
+                                                             const Vec3<T> *__restrict__ force,
+                                                             Vec3<T> *__restrict__ v_star, int *__restrict__ hash,
+                                                             int *__restrict__ slot, int *__restrict__ cellCount,
+                                                             int *__restrict__ undefBlockCount) {
+    __shared__ int waveCount[kBlock / 64];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    Vec4<T> p;
+    p.x = p.y = p.z = p.w = 0;
+    if (valid) {
+        p = posType[i];
+        if (advect_moves(P, unpack_int(p.w))) {
+            Vec4<T> v = velMass[i];
+            Vec3<T> vs;
+            advect_particle(P, p, v, force[i], vs);
+            v_star[i] = vs;
+            posType[i] = p;
+            velMass[i] = v;
+        }
+    }
+    hash_and_count(P, valid, i, p.x, p.y, p.z, hash, slot, cellCount, undefBlockCount, waveCount);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,16 +362,198 @@ __global__ __launch_bounds__(256) void block_rows_kernel(DevParams<float> P, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// The sort of a whole step in four launches (single solvers; z-slab solvers rank by order key and keep the
+// launches above): tile sums and apply of BOTH prefix sums (cell counts, out-of-grid block counts), scatter,
+// rank + reorder + row table.
+// ------------------------------------------------------------------------------------------------
+struct Scan2 {
+    const int *in[2];
+    int *out[2];
+    int n[2];
+    int tiles[2];
+};
+
+__global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(Scan2 a, int *__restrict__ tileSums,
+                                                                 int *__restrict__ big) {
+    __shared__ int smem[kBlock / 64 + 1];
+    if (big && blockIdx.x == 0 && threadIdx.x == 0) big[0] = 0;  // the list of large-tile blocks starts empty
+    const int k = (int)blockIdx.x < a.tiles[0] ? 0 : 1;
+    const int tile = (int)blockIdx.x - (k ? a.tiles[0] : 0);
+    const int *in = a.in[k];
+    const int n = a.n[k];
+    const long long base = (long long)tile * kScanTile + (long long)threadIdx.x * kScanPerThread;
+    int sum = 0;
+    if (base + kScanPerThread <= n) {
+        const int4 u = *reinterpret_cast<const int4 *>(in + base);
+        const int4 v = *reinterpret_cast<const int4 *>(in + base + 4);
+        sum = u.x + u.y + u.z + u.w + v.x + v.y + v.z + v.w;
+    } else {
+        for (int j = 0; j < kScanPerThread; j++)
+            if (base + j < n) sum += in[base + j];
+    }
+    int total;
+    block_exclusive_scan(sum, total, smem);
+    if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+
+// Every block adds up the sums of the tiles before it in its sequence (a few thousand ints out of L2) instead of a
+// single-block launch in between.  Sequence 0's input is set back to zero once read: the cell counts are then
+// ready for the next hash pass.
+__global__ __launch_bounds__(kBlock) void scan2_apply_kernel(Scan2 a, const int *__restrict__ tileSums,
+                                                             int *__restrict__ zero_in0) {
+    __shared__ int smem[kBlock / 64 + 1];
+    const int k = (int)blockIdx.x < a.tiles[0] ? 0 : 1;
+    const int first = k ? a.tiles[0] : 0;
+    const int tile = (int)blockIdx.x - first;
+    const int *in = a.in[k];
+    int *out = a.out[k];
+    const int n = a.n[k];
+    int before = 0;
+    for (int j = threadIdx.x; j < tile; j += kBlock) before += tileSums[first + j];
+    int carry;
+    block_exclusive_scan(before, carry, smem);
+    const long long base = (long long)tile * kScanTile + (long long)threadIdx.x * kScanPerThread;
+    int v[kScanPerThread];
+    const bool full = base + kScanPerThread <= n;
+    if (full) {
+        const int4 u = *reinterpret_cast<const int4 *>(in + base);
+        const int4 w = *reinterpret_cast<const int4 *>(in + base + 4);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+        v[4] = w.x; v[5] = w.y; v[6] = w.z; v[7] = w.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanPerThread; j++) v[j] = (base + j < n) ? in[base + j] : 0;
+    }
+    if (k == 0 && zero_in0) {
+        if (full) {
+            *reinterpret_cast<int4 *>(zero_in0 + base) = make_int4(0, 0, 0, 0);
+            *reinterpret_cast<int4 *>(zero_in0 + base + 4) = make_int4(0, 0, 0, 0);
+        } else {
+            for (int j = 0; j < kScanPerThread; j++)
+                if (base + j < n) zero_in0[base + j] = 0;
+        }
+    }
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) sum += v[j];
+    int total;
+    int run = carry + block_exclusive_scan(sum, total, smem);
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; j++) {
+        if (base + j <= n) out[base + j] = run;  // position n (one past the end) receives the grand total
+        run += v[j];
+    }
+}
+
+// scatter_kernel, and the first arrival of every cell also notes which blocks of kTunedBS sorted positions begin
+// and end inside its cell: the cell of a block's first and of its last particle (blockLo / blockHi), which the row
+// table needs, known here before the particles are in place.
+__global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, int num_cells, const int *__restrict__ hash,
+                                                                const int *__restrict__ slot,
+                                                                const int *__restrict__ cellStart,
+                                                                const int *__restrict__ undefBlockStart,
+                                                                int *__restrict__ tmpIndex,
+                                                                int *__restrict__ tmpHash, int *__restrict__ blockLo,
+                                                                int *__restrict__ blockHi) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const unsigned h = (unsigned)hash[i];
+    const int sl = slot[i];
+    int p;
+    if (h != FSA_GRID_UNDEF) {
+        const int a = cellStart[h];
+        p = a + sl;
+        if (sl == 0) {
+            const int b = cellStart[h + 1], last = min(n, cellStart[num_cells]) - 1;
+            for (int m = (a + kTunedBS - 1) / kTunedBS * kTunedBS; m < b; m += kTunedBS) blockLo[m / kTunedBS] = (int)h;
+            for (int e = a | (kTunedBS - 1); e < b; e += kTunedBS) blockHi[e / kTunedBS] = (int)h;
+            if (last >= a && last < b) blockHi[last / kTunedBS] = (int)h;
+        }
+    } else {
+        p = cellStart[num_cells] + undefBlockStart[blockIdx.x] + sl;
+    }
+    tmpIndex[p] = i;
+    tmpHash[p] = (int)h;
+}
+
+// rank_kernel + reorder_kernel + block_rows_kernel in one pass: the thread that finds the stable place p of source
+// particle i moves the particle there itself (reads as in the gather form, writes permuted inside one cell only),
+// and the first 16 threads of each block write the row-table entry of the block of sorted positions they cover.
+// VSTAR_ALL = false: v_star only travels for particles that are not TYPE_FLUID (the integration rewrites it for
+// every fluid particle before anybody can read it).
+template <typename T, bool VSTAR_ALL>
+__global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
+    DevParams<float> Pf, int n, const int *__restrict__ tmpIndex, const int *__restrict__ tmpHash,
+    const int *__restrict__ cellStart, int *__restrict__ sortedIndex, int *__restrict__ sortedHash,
+    const Vec4<T> *__restrict__ posTypeIn, const Vec4<T> *__restrict__ velMassIn, const T *__restrict__ restDensityIn,
+    const int *__restrict__ uniqueIdIn, const Vec3<T> *__restrict__ vStarIn, Vec4<T> *__restrict__ posTypeOut,
+    Vec4<T> *__restrict__ velMassOut, T *__restrict__ restDensityOut, int *__restrict__ uniqueIdOut,
+    Vec3<T> *__restrict__ vStarOut, const int *__restrict__ blockLo, const int *__restrict__ blockHi,
+    int *__restrict__ table, int *__restrict__ big) {
+    static_assert(kTunedBS == kBlock, "one row-table entry per block of this kernel");
+    const int sIdx = blockIdx.x * kBlock + threadIdx.x;
+    if (table && threadIdx.x < 64) {  // row table (fp32 solvers), as block_rows_kernel
+        const int blk = blockIdx.x, r = threadIdx.x & 15;
+        const int b0 = blk * kTunedBS, nb = min(kTunedBS, n - b0);
+        const int in_grid = cellStart[Pf.num_cells];
+        const unsigned hlo = b0 < in_grid ? (unsigned)blockLo[blk] : (unsigned)FSA_GRID_UNDEF;
+        const unsigned hhi = b0 + nb - 1 < in_grid ? (unsigned)blockHi[blk] : (unsigned)FSA_GRID_UNDEF;
+        const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
+        int bad = grid_ok ? 0 : 1, longest = 0;
+        int *row = table + (size_t)blk * kRowTableStride;
+        if (r < 9) {
+            int st, len;
+            block_row(Pf, hlo, hhi, grid_ok, r, cellStart, st, len);
+            if (threadIdx.x < 16) {
+                row[r] = st;
+                row[9 + r] = len;
+            }
+            if (len < 0 || len > kRowCapBig) bad = 1;
+            longest = len;
+        }
+        for (int d = 8; d >= 1; d >>= 1) {
+            bad |= __shfl_xor(bad, d, 16);
+            longest = max(longest, __shfl_xor(longest, d, 16));
+        }
+        if (threadIdx.x == 0) {
+            const int cls = bad ? 0 : (longest <= kRowCap ? 1 : 2);
+            row[18] = cls;
+            row[19] = 0;
+            if (cls == 2) big[1 + atomicAdd(&big[0], 1)] = blk;  // any order: the blocks are independent
+        }
+    }
+    if (sIdx >= n) return;
+    const int i = tmpIndex[sIdx];
+    const unsigned h = (unsigned)tmpHash[sIdx];
+    int p = sIdx;  // out-of-grid particles are already in stable order
+    if (h != FSA_GRID_UNDEF) {
+        const int a = cellStart[h], b = cellStart[h + 1];
+        int r = 0;
+        for (int t = a; t < b; t++) r += (tmpIndex[t] < i) ? 1 : 0;
+        p = a + r;
+    }
+    sortedIndex[p] = i;
+    sortedHash[p] = (int)h;
+    const Vec4<T> pt = posTypeIn[i];
+    posTypeOut[p] = pt;
+    velMassOut[p] = velMassIn[i];
+    restDensityOut[p] = restDensityIn[i];
+    uniqueIdOut[p] = uniqueIdIn[i];
+    if (VSTAR_ALL || unpack_int(pt.w) != FSA_TYPE_FLUID) vStarOut[p] = vStarIn[i];  // sortedV_star, :168
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 int launch_hash_count(Solver *s) {
     const int n = s->n, nb = blocks_for(n);
-    {
+    if (!s->counts_clean) {
         ScopedTimer t(s, "clear_counts");
         FSA_HIP(hipMemsetAsync(s->b.cellCount, 0, (size_t)s->num_cells * sizeof(int), s->stream));
     }
+    s->counts_clean = n == 0;
     if (n == 0) return FSA_OK;
     ScopedTimer t(s, "hash_count");
     if (s->precision == FSA_PRECISION_F32)
@@ -398,6 +624,90 @@ int launch_reorder(Solver *s) {
         FSA_HIP(hipGetLastError());
     }
     if (s->slab) return launch_slab_keys(s);
+    if (s->iisph) return launch_iisph_carry(s, out);
+    return FSA_OK;
+}
+
+// hash + counts of the current positions; `with_advect`: integrate first, in the same pass
+int launch_hash_fused(Solver *s, bool with_advect) {
+    const int n = s->n, nb = blocks_for(n);
+    if (!s->counts_clean) {
+        ScopedTimer t(s, "clear_counts");
+        FSA_HIP(hipMemsetAsync(s->b.cellCount, 0, (size_t)s->num_cells * sizeof(int), s->stream));
+        s->counts_clean = true;
+    }
+    if (n == 0) return FSA_OK;
+    if (!with_advect) return launch_hash_count(s);
+    ScopedTimer t(s, "advect_hash");
+    s->lists_valid = false;  // positions move
+    s->hits_valid = false;
+    s->counts_clean = false;
+    const int c = s->cur;
+    if (s->precision == FSA_PRECISION_F32)
+        hipLaunchKernelGGL(advect_hash_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, s->pf, n,
+                           (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c], (const Vec3<float> *)s->b.force,
+                           (Vec3<float> *)s->b.v_star, s->b.hash, s->b.slot, s->b.cellCount, s->b.undefBlockCount);
+    else
+        hipLaunchKernelGGL(advect_hash_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, s->pd, n,
+                           (double4 *)s->b.posType[c], (double4 *)s->b.velMass[c], (const Vec3<double> *)s->b.force,
+                           (Vec3<double> *)s->b.v_star, s->b.hash, s->b.slot, s->b.cellCount, s->b.undefBlockCount);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// fsa_sort_particle + fsa_reorder_data_and_find_cell_start of a single (not z-slab) solver in four launches;
+// hash / slot / cellCount must describe the current arrays.  Leaves cellCount zeroed.
+int launch_sort_fused(Solver *s, bool vstar_all) {
+    const int n = s->n, nb = blocks_for(n), C = s->num_cells;
+    Scan2 a;
+    a.in[0] = s->b.cellCount;
+    a.out[0] = s->b.cellStart;
+    a.n[0] = C;
+    a.tiles[0] = (C + 1 + kScanTile - 1) / kScanTile;
+    a.in[1] = s->b.undefBlockCount;
+    a.out[1] = s->b.undefBlockStart;
+    a.n[1] = nb;
+    a.tiles[1] = n ? (nb + 1 + kScanTile - 1) / kScanTile : 0;
+    {
+        ScopedTimer t(s, "scan_sums");
+        hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(a.tiles[0] + a.tiles[1]), dim3(kBlock), 0, s->stream, a,
+                           s->b.scanTmp, s->b.bigBlocks);
+    }
+    {
+        ScopedTimer t(s, "scan_apply");
+        hipLaunchKernelGGL(scan2_apply_kernel, dim3(a.tiles[0] + a.tiles[1]), dim3(kBlock), 0, s->stream, a,
+                           (const int *)s->b.scanTmp, s->b.cellCount);
+    }
+    FSA_HIP(hipGetLastError());
+    s->counts_clean = true;
+    if (n == 0) return FSA_OK;
+    {
+        ScopedTimer t(s, "scatter");
+        hipLaunchKernelGGL(scatter_bounds_kernel, dim3(nb), dim3(kBlock), 0, s->stream, n, C, s->b.hash, s->b.slot,
+                           s->b.cellStart, s->b.undefBlockStart, s->b.tmpIndex, s->b.tmpHash, s->b.blockLo,
+                           s->b.blockHi);
+    }
+    const int in = s->cur, out = 1 - s->cur;
+    {
+        ScopedTimer t(s, "rank_reorder");
+        const bool f32 = s->precision == FSA_PRECISION_F32;
+#define FSA_RR(T, T4, ALL)                                                                                           \
+    hipLaunchKernelGGL((rank_reorder_kernel<T, ALL>), dim3(nb), dim3(kBlock), 0, s->stream, s->pf, n, s->b.tmpIndex, \
+                       s->b.tmpHash, s->b.cellStart, s->b.sortedIndex, s->b.sortedHash,                              \
+                       (const T4 *)s->b.posType[in], (const T4 *)s->b.velMass[in], (const T *)s->b.restDensity[in],  \
+                       s->b.uniqueId[in], (const Vec3<T> *)s->b.v_star, (T4 *)s->b.posType[out],                     \
+                       (T4 *)s->b.velMass[out], (T *)s->b.restDensity[out], s->b.uniqueId[out],                      \
+                       (Vec3<T> *)s->b.v_star_alt, s->b.blockLo, s->b.blockHi, f32 ? s->b.blockRows : nullptr,       \
+                       s->b.bigBlocks)
+        if (f32) {
+            if (vstar_all) FSA_RR(float, float4, true); else FSA_RR(float, float4, false);
+        } else {
+            if (vstar_all) FSA_RR(double, double4, true); else FSA_RR(double, double4, false);
+        }
+#undef FSA_RR
+        FSA_HIP(hipGetLastError());
+    }
+    std::swap(s->b.v_star, s->b.v_star_alt);
     if (s->iisph) return launch_iisph_carry(s, out);
     return FSA_OK;
 }

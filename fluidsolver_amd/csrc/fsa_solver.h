@@ -58,6 +58,8 @@ struct Buffers {
     int *gridCellEnd = nullptr;
     int *blockRows = nullptr;    // row table of the tiled passes, rebuilt by every reorder (fp32)
     int *bigBlocks = nullptr;    // count, then ids of the blocks that need the large tiles
+    int *blockLo = nullptr;      // cell of the first / last particle of every block of kTunedBS sorted positions
+    int *blockHi = nullptr;
     unsigned short *nbList = nullptr;   // recorded neighbour lists (allocated on first use), see fsa_tile.h
     unsigned short *nbCount = nullptr;  // entries per particle
     void *hitWords = nullptr;           // recorded hits of the WCSPH passes (fp32), see fsa_tile.h
@@ -95,6 +97,9 @@ struct Solver {
     hipStream_t stream = nullptr;
     // call-order state
     bool hash_valid = false;    // hash/slot/cellCount describe the current arrays
+    bool hash_ahead = false;    // the same, computed by the last step's integration pass (fsa_step); not what
+                                // the reference's particleHash holds after Advect, so read-back ignores it
+    bool counts_clean = true;   // cellCount[] is all zero (as allocated; the fused scan leaves it so)
     bool perm_valid = false;    // sortedIndex/sortedHash/cellStart computed from hash
     bool sorted_valid = false;  // current arrays are in sorted order and cellStart matches them
     bool index_table_valid = false;
@@ -145,6 +150,8 @@ struct ScopedTimer {
 
 // ---- launchers (fsa_grid.hip, fsa_sph.hip) ---------------------------------
 int launch_hash_count(Solver *s);
+int launch_hash_fused(Solver *s, bool with_advect);
+int launch_sort_fused(Solver *s, bool vstar_all);
 int launch_scan_cells(Solver *s);
 int launch_scatter(Solver *s);
 int launch_rank(Solver *s);

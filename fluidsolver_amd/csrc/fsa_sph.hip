@@ -11,6 +11,7 @@
 // row are adjacent in the sorted arrays: the walk below visits 9 contiguous index ranges
 // [cellStart[row + xlo], cellStart[row + xhi + 1]) and thereby meets the neighbours in exactly the
 // reference's order (the per-particle sums are accumulated in that order).
+#include "fsa_advect.h"
 #include "fsa_pair.h"
 #include "fsa_solver.h"
 
@@ -85,40 +86,11 @@ __global__ __launch_bounds__(kBlock) void advect_kernel(DevParams<T> P, int n, V
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index >= n) return;
     Vec4<T> p = posType[index];
-    const int type = unpack_int(p.w);
-    if (type == FSA_TYPE_RIGID) return;
-    if (P.boundary_mode == FSA_BOUNDARY_LEGACY_CLAMP && type == FSA_TYPE_BOUNDARY) return;
+    if (!advect_moves(P, unpack_int(p.w))) return;
     Vec4<T> v = velMass[index];
-    const Vec3<T> f = force[index];
-    v.x += f.x * P.dt;
-    v.y += f.y * P.dt;
-    v.z += f.z * P.dt;
-    p.x += v.x * P.dt;
-    p.y += v.y * P.dt;
-    p.z += v.z * P.dt;
-
-    T ax = P.gravity[0] - f.x, ay = P.gravity[1] - f.y, az = P.gravity[2] - f.z;
-    const T magnitude = r_sqrt(ax * ax + ay * ay + az * az);
-    if (magnitude > P.accel_limit) {
-        ax = ax / magnitude * P.accel_limit;
-        ay = ay / magnitude * P.accel_limit;
-        az = az / magnitude * P.accel_limit;
-    }
     Vec3<T> vs;
-    vs.x = P.gravity[0] - ax;
-    vs.y = P.gravity[1] - ay;
-    vs.z = P.gravity[2] - az;
+    advect_particle(P, p, v, force[index], vs);
     v_star[index] = vs;
-
-    if (P.boundary_mode == FSA_BOUNDARY_LEGACY_CLAMP) {
-        // clampBoundary, solver/新建文件夹/sph_kernel_impl.cuh:365-392: order y, x, z
-        if ((double)p.y < (double)P.gmin[1] + FSA_EPSILON) { p.y = (T)((double)P.gmin[1] + FSA_EPSILON); v.y = 0; }
-        if ((double)p.y > (double)P.gmax[1] - FSA_EPSILON) { p.y = (T)((double)P.gmax[1] - FSA_EPSILON); v.y = 0; }
-        if ((double)p.x < (double)P.gmin[0] + FSA_EPSILON) { p.x = (T)((double)P.gmin[0] + FSA_EPSILON); v.x = 0; }
-        if ((double)p.x > (double)P.gmax[0] - FSA_EPSILON) { p.x = (T)((double)P.gmax[0] - FSA_EPSILON); v.x = 0; }
-        if ((double)p.z < (double)P.gmin[2] + FSA_EPSILON) { p.z = (T)((double)P.gmin[2] + FSA_EPSILON); v.z = 0; }
-        if ((double)p.z > (double)P.gmax[2] - FSA_EPSILON) { p.z = (T)((double)P.gmax[2] - FSA_EPSILON); v.z = 0; }
-    }
     posType[index] = p;
     velMass[index] = v;
 }
