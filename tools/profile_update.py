@@ -5,7 +5,7 @@ refresh profiles/traffic.json (HBM-side bytes per launch = (2 x FETCH_SIZE + WRI
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def parse(path):
@@ -24,8 +24,8 @@ def find(d, prefix):
 
 
 f, w, q = (parse(os.path.join(SRC, n)) for n in ("pmc_fetch.txt", "pmc_write.txt", "pmc_sq.txt"))
-kernels = {"force": "force_tuned_kernel", "density": "density_tuned_kernel", "advect": "advect_kernel",
-           "reorder": "reorder_kernel", "hash_count": "hash_count_kernel"}
+kernels = {"force": "force_rows_kernel", "density": "density_record_kernel", "advect_hash": "advect_hash_kernel",
+           "rank_reorder": "rank_reorder_kernel", "scatter": "scatter_bounds_kernel"}
 t = json.load(open(os.path.join(DST, "traffic.json")))
 for key, k in kernels.items():
     t["dam16m:" + key] = (2 * find(f, k)["FETCH_SIZE"] + find(w, k)["WRITE_SIZE"]) * 1024
