@@ -25,8 +25,23 @@ def test_scene():
     return sc
 
 
+def ddam_scene():
+    """small double dam break with box obstacles (two fluid blocks, obstacles staggered along z): the particle
+    count per layer is uneven and shifts as the blocks collapse"""
+    from fluidsolver_amd import scenes
+    sc = scenes.double_dam_break(8, 8, 20, tank_x_factor=3.0)
+    n_fluid = sc["n_fluid"]
+    sc = scenes.jittered(sc, seed=78, pos_jitter=0.2, vel_scale=1.5, fluid_only=True)
+    sc["n_fluid"] = n_fluid
+    return sc
+
+
+SCENES = {"dam": test_scene, "ddam": ddam_scene}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", choices=sorted(SCENES), default="dam")
     ap.add_argument("--rank", type=int, required=True)
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, required=True)
@@ -42,7 +57,7 @@ def main():
     from fluidsolver_amd import slabs
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
-    sc = test_scene()
+    sc = SCENES[a.scene]()
     if a.backend == "oracle":
         from oracle.orc import Oracle
         from slab_oracle_backend import OracleSlabBackend

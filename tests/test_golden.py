@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import oracle_pair, rel_err
+from util import elem_err, force_err, oracle_pair, rel_err
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = {"f32": 1e-5, "f64": 1e-10}
@@ -73,14 +73,17 @@ def test_hip_matches_golden(precision, variant):
     assert np.array_equal(s.get("uniqueId"), g["sorted_uniqueId"])
     assert np.array_equal(s.get("indexTable"), g["indexTable"])
     s.compute_pressure()
-    assert rel_err(s.get("density"), g["density"]) <= tol
-    assert rel_err(s.get("pressure"), g["pressure"]) <= tol
+    # per element; the pressure floor is what the equation of state makes of a density error (tests/test_gpu_parity.py)
+    rd = s.get("restDensity").astype(np.float64)
+    assert elem_err(s.get("density"), g["density"], 1e-3 * rd) <= tol
+    cond = 7.0 * sc["params"]["pressureK"] * (g["density"].astype(np.float64) / rd) ** 7
+    assert elem_err(s.get("pressure"), g["pressure"], cond) <= tol
     # the force pass from the golden density / pressure, so that its own error is what is measured
     s.set("density", g["density"])
     s.set("pressure", g["pressure"])
     s.compute_force()
     fluid = sc["type"][g["particleIndex"]] == 0
-    assert rel_err(s.get("force")[fluid], g["force"][fluid]) <= tol
+    assert force_err(s.get("force")[fluid], g["force"][fluid]) <= tol
     s.set("force", g["force"])
     s.advect()
     if precision == "f32":
@@ -136,9 +139,14 @@ def test_hip_iisph_matches_golden(precision, variant):
     s.set("density_star", g["density_star"])
     rounds, _ = s.iisph_solve_pressure(10)
     assert rounds == int(g["rounds"])  # the fixture was made with the mean taken in double, as the library does
+    # ten relaxed-Jacobi rounds, each dividing by a_ii (a small difference of large sums) and feeding the result to
+    # the next: the per-round rounding difference of the two pair sums grows by about one order per few rounds, so
+    # the solved pressure is held to 1e-3 of the largest pressure, not to the per-pass 1e-5
     assert rel_err(s.get("pressure")[fluid], g["pressure"][fluid]) <= 100 * tol
     s.set("pressure", g["pressure"])
     s.iisph_update()
     assert rel_err(s.get("pressureForce")[fluid], g["pressureForce"][fluid]) <= tol
+    # velocity = old velocity + dt * (v_star + pressure force), compared against the largest speed: the pressure
+    # force carries the 1e-5 of its own pass times dt / |v|
     assert rel_err(s.get("vel"), g["vel_after"]) <= 10 * tol
     s.close()

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from fluidsolver_amd import capi, scenes
-from util import gpu_solver, oracle_pair, rel_err
+from util import elem_err, force_err, gpu_solver, oracle_pair, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -47,12 +47,15 @@ def test_fp64_step_stages(pair64):
         assert rel_err(s.get("restDensity"), st["restDensity"]) <= TOL
     st.compute_pressure(p_o)
     s.compute_pressure()
-    assert rel_err(s.get("density"), st["density"]) <= TOL
-    assert rel_err(s.get("pressure"), st["pressure"]) <= TOL
+    # per element; the pressure floor is what the equation of state makes of a density error (tests/test_gpu_parity.py)
+    rd = st["restDensity"].astype(np.float64)
+    assert elem_err(s.get("density"), st["density"], 1e-3 * rd) <= TOL
+    cond = 7.0 * sc["params"]["pressureK"] * (st["density"].astype(np.float64) / rd) ** 7
+    assert elem_err(s.get("pressure"), st["pressure"], cond) <= TOL
     st.compute_force(p_o)
     s.compute_force()
     fluid = st["type"] == 0
-    assert rel_err(s.get("force")[fluid], st["force"][fluid]) <= TOL
+    assert force_err(s.get("force")[fluid], st["force"][fluid]) <= TOL
     st.advect(p_o)
     s.advect()
     assert rel_err(s.get("pos"), st["pos"]) <= TOL

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from fluidsolver_amd import capi, scenes
-from util import rel_err
+from util import elem_err, force_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -67,8 +67,8 @@ def test_tuned_kernels_agree_with_generic_full_size(big):
     fluid = s.get("type") == 0
     # variant 3 replays the hits its density pass recorded: the bits of variant 2
     assert np.array_equal(out[3][0], out[2][0]) and np.array_equal(out[3][1][fluid], out[2][1][fluid])
-    assert rel_err(out[2][0], out[0][0]) <= 1e-5
-    assert rel_err(out[2][1][fluid], out[0][1][fluid]) <= 1e-5
+    assert elem_err(out[2][0], out[0][0], 1.0) <= 1e-5                   # per element
+    assert force_err(out[2][1][fluid], out[0][1][fluid]) <= 1e-5         # per particle, floor = median |f|
     assert np.all(out[2][0][fluid] > 0)  # a fluid particle counts itself; walls only count fluid neighbours
 
 

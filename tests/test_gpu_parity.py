@@ -1,12 +1,19 @@
 """GPU parity: every stage of the HIP path, called through the C ABI, against the CPU oracle on the
 same inputs.  Integer outputs (cell hash, sorted order, cell ranges, index table) must be bit-exact;
-floating-point outputs must agree within 1e-5 relative (fp32) as the tolerance written in each test.
+floating-point outputs must agree within 1e-5 relative (fp32), PER ELEMENT (tests/util.py: elem_err, force_err):
+  density   |d - d_o| <= 1e-5 max(|d_o|, 1e-3 rest density);
+  pressure  |p - p_o| <= 1e-5 max(|p_o|, 7 K (rho/rho0)^7): the equation of state subtracts 1 from (rho/rho0)^7,
+            so near the rest density a relative error e of the density (or one rounding of powf) shows up as an
+            absolute error 7 K (rho/rho0)^7 e of the pressure, however small the pressure itself is;
+  force     |f_i - f_o,i| <= 1e-5 max(|f_o,i|, median_k |f_o,k|) per particle, Euclidean norms.
+Measured (tools/parity_errs.py): the exact variants give the oracle's density and force bit for bit, the fast ones
+stay below 2.1e-6 (density) and 5.3e-7 (force).
 """
 import numpy as np
 import pytest
 
 from fluidsolver_amd import scenes
-from tests.util import gpu_solver, oracle_pair, rel_err, ulp_diff
+from tests.util import elem_err, force_err, gpu_solver, oracle_pair, rel_err, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -129,14 +136,16 @@ def test_density_pressure(pair):
     st.compute_pressure(p_o)
     s.compute_pressure()
     d_g, d_o = s.get("density"), st["density"]
-    assert rel_err(d_g, d_o) <= TOL
+    rd = st["restDensity"].astype(np.float64)
+    assert elem_err(d_g, d_o, 1e-3 * rd) <= TOL
     if s.exact_arithmetic:
         # same operation order and correctly rounded sqrt/div: the sums should match to the last bit
         assert ulp_diff(d_g, d_o) <= 2
     pr_g, pr_o = s.get("pressure"), st["pressure"]
     ok = np.isfinite(pr_o)
     assert np.array_equal(np.isfinite(pr_g), ok)
-    assert rel_err(pr_g[ok], pr_o[ok]) <= TOL
+    cond = 7.0 * sc["params"]["pressureK"] * (d_o[ok].astype(np.float64) / rd[ok]) ** 7  # see the module docstring
+    assert elem_err(pr_g[ok], pr_o[ok], cond) <= TOL
 
 
 def test_force_from_same_state(pair):
@@ -154,6 +163,8 @@ def test_force_from_same_state(pair):
     ok = np.isfinite(f_o).all(axis=1)
     assert np.array_equal(np.isfinite(f_g).all(axis=1), ok)
     assert ok.sum() > 0.9 * len(ok)
+    fluid = ok & (st["type"] == 0)  # other types keep whatever force[] held
+    assert force_err(f_g[fluid], f_o[fluid]) <= (1e-6 if s.exact_arithmetic else TOL)
     assert rel_err(f_g[ok], f_o[ok]) <= TOL
 
 
@@ -192,7 +203,11 @@ def test_full_steps_track_oracle(orc32, variant):
     vel_o = np.empty_like(st["vel"]); vel_o[uid_o] = st["vel"]
     scale = float(np.abs(np.array(sc["params"]["vmax"]) - np.array(sc["params"]["vmin"])).max())
     assert np.abs(pos_g.astype(np.float64) - pos_o).max() <= TOL * scale
-    assert rel_err(vel_g, vel_o) <= 1e-3   # velocities amplify rounding differences over 20 steps
+    # After 20 steps the two runs are no longer in the same state: every step adds dt * (force difference) to the
+    # velocities, and a force difference of 1e-5 of the largest force is, with these parameters, 1e-4 of the largest
+    # speed per step.  So this is a trajectory bound (against the largest speed), not a per-pass parity bar; the
+    # per-pass bars are in the tests above and in tests/test_gpu_developed.py.
+    assert rel_err(vel_g, vel_o) <= 1e-3
     same_order = (uid_g == uid_o).mean()
     assert same_order > 0.99
     s.close(); st.close()
@@ -216,10 +231,10 @@ def test_rigid_particle_volume_and_reference_scene(orc32, variant):
     st.compute_pressure(p_o); s.compute_pressure()
     fluid = st["type"] == 0
     assert (st["type"] == 4).sum() > 10000
-    assert rel_err(s.get("density")[fluid], st["density"][fluid]) <= TOL
+    assert elem_err(s.get("density")[fluid], st["density"][fluid], 1.0) <= TOL
     s.set("density", st["density"]); s.set("pressure", st["pressure"])
     st.compute_force(p_o); s.compute_force()
-    assert rel_err(s.get("force")[fluid], st["force"][fluid]) <= TOL
+    assert force_err(s.get("force")[fluid], st["force"][fluid]) <= TOL
     s.set("force", st["force"])
     st.advect(p_o); s.advect()
     assert np.array_equal(s.get("pos").view(np.int32), st["pos"].view(np.int32))

@@ -24,11 +24,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0):
+def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0, scene="dam"):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "--rank", str(r), "--world",
                                str(world), "--port", str(port), "--out", str(out), "--backend", backend, "--steps",
-                               str(steps), "--variant", str(variant), "--recut-at", str(recut_at)])
+                               str(steps), "--variant", str(variant), "--recut-at", str(recut_at), "--scene", scene])
              for r in range(world)]
     try:
         codes = [p.wait(timeout=timeout) for p in procs]
@@ -40,9 +40,9 @@ def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0):
     return [dict(np.load(os.path.join(out, f"rank{r}.npz"))) for r in range(world)]
 
 
-def undivided(orc, steps):
-    from slab_worker import test_scene
-    sc = test_scene()
+def undivided(orc, steps, scene="dam"):
+    from slab_worker import SCENES
+    sc = SCENES[scene]()
     p, st = oracle_pair(orc, sc)
     for _ in range(steps - 1):
         st.solve_sph(p, 1)
@@ -102,6 +102,21 @@ def test_recut_mid_run_keeps_the_run_bit_identical(orc32, tmp_path):
     counts = np.array([int(p["owned_count"]) for p in parts], float)
     assert counts.max() / counts.mean() < 1.35
     assert list(parts[0]["cuts"]) != [0, 3, 6, int(parts[0]["cuts"][-1])]
+
+
+def test_double_dam_with_obstacles_recut(orc32, tmp_path):
+    """the double dam break with box obstacles (uneven, shifting particle count per layer) over two ranks, from
+    lopsided cuts, with one rebalance() on the way: still the undivided run bit for bit"""
+    steps = 25
+    parts = run_ranks(2, "oracle", steps, tmp_path, recut_at=10, scene="ddam")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    assert sum(int(p["sent"]) for p in parts) > 0
+    sc, ref = undivided(orc32, steps, scene="ddam")
+    assert (sc["type"] != 0).sum() > 0 and len(np.unique(sc["group"])) >= 4  # walls, obstacles, two fluid blocks
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, ref)
+    counts = np.array([int(p["owned_count"]) for p in parts], float)
+    assert counts.max() / counts.mean() < 1.35
 
 
 def test_balanced_cuts():
