@@ -252,6 +252,9 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     to_dev_params(*p, s->pd);
     s->num_cells = s->pf.num_cells;
     s->slab = p->slab_nz > 0;
+    // experiment switches, read here once and never in a launch path
+    if (const char *e = getenv("FSA_XCD_RUN_LOG")) s->xcd_run_log = std::min(12, std::max(0, atoi(e)));
+    if (const char *e = getenv("FSA_FAST_DBG")) s->dbg_fast = atoi(e);
 
     int rc = activate(s);
     if (rc == FSA_OK && hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess)
@@ -329,6 +332,12 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     }
     s->pf.rows = s->b.blockRows;
     s->pf.big = s->b.bigBlocks;
+    // the zero fills above ran on the NULL stream, which the solver's non-blocking stream does not wait for
+    if (hipDeviceSynchronize() != hipSuccess) {
+        free_all(s);
+        delete s;
+        return fail(FSA_ERR_HIP, "hipDeviceSynchronize failed after the allocations");
+    }
     *out = reinterpret_cast<fsa_solver *>(s);
     return FSA_OK;
 }
@@ -438,7 +447,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     // colour, normal and group never change on this path: keep them in uniqueId order
     auto store_static = [&](void *dst, const void *src, size_t elem_bytes) -> int {
         if (!src) {
-            FSA_HIP(hipMemset(dst, 0, N * elem_bytes));
+            FSA_HIP(hipMemsetAsync(dst, 0, N * elem_bytes, s->stream));  // waited for at the end of fsa_upload
             return FSA_OK;
         }
         std::vector<unsigned char> tmp(N * elem_bytes);
@@ -452,11 +461,12 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
         TRY(store_static(s->b.normal, normal3, 3 * R));
         TRY(store_static(s->b.group, group, sizeof(int)));
     }
-    // start from the zero state the constructor gives
-    FSA_HIP(hipMemset(s->b.force, 0, N * 3 * R));
-    FSA_HIP(hipMemset(s->b.v_star, 0, N * 3 * R));
-    FSA_HIP(hipMemset(s->b.density, 0, N * R));
-    FSA_HIP(hipMemset(s->b.pressure, 0, N * R));
+    // start from the zero state the constructor gives (on the solver's own stream, which does not wait for the
+    // NULL stream)
+    FSA_HIP(hipMemsetAsync(s->b.force, 0, N * 3 * R, s->stream));
+    FSA_HIP(hipMemsetAsync(s->b.v_star, 0, N * 3 * R, s->stream));
+    FSA_HIP(hipMemsetAsync(s->b.density, 0, N * R, s->stream));
+    FSA_HIP(hipMemsetAsync(s->b.pressure, 0, N * R, s->stream));
     FSA_HIP(hipStreamSynchronize(s->stream));
     return FSA_OK;
 }

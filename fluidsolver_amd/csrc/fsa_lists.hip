@@ -138,23 +138,29 @@ int ensure_lists(Solver *s) {
         hipError_t e = hipMalloc(&lists, blocks * kListSlots * kTunedBS * sizeof(unsigned short));
         if (e == hipSuccess) e = hipMalloc(&counts, blocks * kTunedBS * sizeof(unsigned short));
         if (e != hipSuccess) {
+            // no memory for the lists: the searching kernels give the same bits without them, so carry on with
+            // those (fsa_last_error keeps the note; fsa_set_neighbour_lists(s, 1) tries again)
             if (lists) (void)hipFree(lists);
-            return fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour lists (%zu blocks of %d particles) failed: %s", blocks,
-                        kTunedBS, hipGetErrorString(e));
+            (void)hipGetLastError();
+            s->use_lists = false;
+            s->lists_valid = false;
+            (void)fail(FSA_ERR_NOMEM, "hipMalloc of the neighbour lists (%zu blocks of %d particles) failed: %s; "
+                       "the passes search instead", blocks, kTunedBS, hipGetErrorString(e));
+            return FSA_OK;
         }
         s->b.nbList = (unsigned short *)lists;
         s->b.nbCount = (unsigned short *)counts;
     }
     ScopedTimer t(s, "list_build");
-    const int unit = kXcds << xcd_run_log();
+    const int unit = kXcds << s->xcd_run_log;
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
     hipLaunchKernelGGL((list_build_kernel<kTunedBS, kRowCap, kQueueL, kListSlots>), dim3(nb), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->n, (const float4 *)s->b.posType[s->cur], s->b.cellStart, s->b.sortedHash,
-                       s->b.nbList, s->b.nbCount, xcd_run_log());
+                       s->b.nbList, s->b.nbCount, s->xcd_run_log);
     if (s->pf.big)  // blocks with rows beyond kRowCap: large tiles, entries with 10 index bits
         hipLaunchKernelGGL((list_build_kernel<kTunedBS, kRowCapBig, kQueueL, kListSlots>), dim3((s->n + kTunedBS - 1) / kTunedBS),
                            dim3(kTunedBS), 0, s->stream, s->pf, s->n, (const float4 *)s->b.posType[s->cur],
-                           s->b.cellStart, s->b.sortedHash, s->b.nbList, s->b.nbCount, xcd_run_log());
+                           s->b.cellStart, s->b.sortedHash, s->b.nbList, s->b.nbCount, s->xcd_run_log);
     FSA_HIP(hipGetLastError());
     s->lists_valid = true;
     return FSA_OK;

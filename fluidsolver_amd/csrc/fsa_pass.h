@@ -414,19 +414,19 @@ static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F3
 // Policy<float> over arrays A through the tiled kernel, or, with `lists`, through the recorded neighbour lists
 // (worth it for passes that run many times per sort; the policy must not reach any type beyond the support).
 template <typename Policy> static int run_tiled(Solver *s, const PassArrays<float> &A, bool lists) {
-    const int unit = kXcds << xcd_run_log();
+    const int unit = kXcds << s->xcd_run_log;
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
     if (lists && s->use_lists && s->lists_valid)
         hipLaunchKernelGGL((list_pass_kernel<Policy, kTunedBS, kListSlots>), dim3(nb), dim3(kTunedBS), 0, s->stream,
-                           s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, xcd_run_log());
+                           s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, s->xcd_run_log);
     else
     {
         hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
-                           s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, xcd_run_log());
+                           s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, s->xcd_run_log);
         if (s->pf.big)  // blocks with rows beyond kRowCap: large tiles, launched over the list of such blocks
             hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCapBig, kQueueDf>),
                                dim3((s->n + kTunedBS - 1) / kTunedBS), dim3(kTunedBS), 0, s->stream, s->pf, s->n, A,
-                               s->b.cellStart, s->b.sortedHash, xcd_run_log());
+                               s->b.cellStart, s->b.sortedHash, s->xcd_run_log);
     }
     FSA_HIP(hipGetLastError());
     return FSA_OK;

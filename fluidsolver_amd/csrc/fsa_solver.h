@@ -117,6 +117,12 @@ struct Solver {
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
     int variant = 3;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32,
                       // 3 as 2 with one neighbour search per step (fsa_sph_fast.hip; same bits as 2)
+    int xcd_run_log = 6;  // log2 of the run of consecutive blocks handed to one XCD (fsa_tile.h); FSA_XCD_RUN_LOG,
+                          // read once by fsa_create, overrides it for experiments
+    // timing experiments (debug_time_pass): parts of the tuned passes switched off, results to scratch arrays
+    int dbg_ablate = 0;
+    void *dbg_out0 = nullptr, *dbg_out1 = nullptr;
+    int dbg_fast = 0;     // FSA_FAST_DBG, likewise read once: experiment flags of the variant-3 kernels
     // timing
     bool timing = false;
     std::vector<std::string> kernel_names;

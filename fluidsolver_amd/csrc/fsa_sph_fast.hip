@@ -563,7 +563,6 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int fast_dbg() { const char *e = getenv("FSA_FAST_DBG"); return e ? atoi(e) : 0; }  // experiments
 constexpr int kQueueD = 10;  // density queue: 4-byte slots (with the tile: 19.6 KB of LDS per workgroup)
 
 static inline int tiled_grid(const Solver *s, int run_log) {
@@ -572,7 +571,7 @@ static inline int tiled_grid(const Solver *s, int run_log) {
 }
 
 template <bool EVAL> static int launch_density_record(Solver *s) {
-    const int c = s->cur, run_log = xcd_run_log() | (fast_dbg() << 8);
+    const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
     hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, run_log)),
                        dim3(kTunedBS), 0, s->stream, s->pf, s->n, (const float4 *)s->b.posType[c],
                        (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
@@ -602,7 +601,7 @@ int launch_force_fast(Solver *s) {
         if (rc) return rc;
     }
     ScopedTimer t(s, "force");
-    const int c = s->cur, run_log = xcd_run_log() | (fast_dbg() << 8);
+    const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
     hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, run_log)), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                        (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,

@@ -40,9 +40,6 @@
 
 namespace fsa {
 
-static int g_ablate = 0;        // timing experiments only (debug_time_pass)
-static void *g_out0 = nullptr;  // when set, results go to these scratch arrays instead
-static void *g_out1 = nullptr;
 
 // ------------------------------------------------------------------------------------------------
 // density + pressure.  Scenes with TYPE_RIGID particles use the generic kernel (the rigid term
@@ -450,14 +447,14 @@ constexpr int kQueueF = 48;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
     if (s->n == 0) return FSA_OK;
-    if (s->variant == 3 && !g_out0) return launch_density_fast(s);
-    ScopedTimer t(s, g_out0 ? "density_dbg" : "density");
+    if (s->variant == 3 && !s->dbg_out0) return launch_density_fast(s);
+    ScopedTimer t(s, s->dbg_out0 ? "density_dbg" : "density");
     const int c = s->cur;
-    const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
+    const int unit = kXcds << s->xcd_run_log;  // the grid is rounded up to whole runs
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-    const int ablate = (g_ablate & 255) | (xcd_run_log() << 8);
-    float *out0 = (float *)(g_out0 ? g_out0 : s->b.density), *out1 = (float *)(g_out1 ? g_out1 : s->b.pressure);
-    float2 *pd_out = g_out0 ? nullptr : (float2 *)s->b.pd;  // not in timing experiments
+    const int ablate = (s->dbg_ablate & 255) | (s->xcd_run_log << 8);
+    float *out0 = (float *)(s->dbg_out0 ? s->dbg_out0 : s->b.density), *out1 = (float *)(s->dbg_out1 ? s->dbg_out1 : s->b.pressure);
+    float2 *pd_out = s->dbg_out0 ? nullptr : (float2 *)s->b.pd;  // not in timing experiments
     if (s->variant >= 2)
         hipLaunchKernelGGL((density_tuned_kernel<kTunedBS, kRowCap, kQueueD, true>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
@@ -493,12 +490,12 @@ int launch_force_tuned(Solver *s) {
                                (const float *)s->b.pressure, (float2 *)s->b.pd);
     }
     // scenes with TYPE_RIGID particles run another density kernel, which records nothing: they keep the search
-    if (s->variant == 3 && !g_out0 && !s->has_rigid) return launch_force_fast(s);
-    ScopedTimer t(s, g_out0 ? "force_dbg" : "force");
-    const int unit = kXcds << xcd_run_log();  // the grid is rounded up to whole runs
+    if (s->variant == 3 && !s->dbg_out0 && !s->has_rigid) return launch_force_fast(s);
+    ScopedTimer t(s, s->dbg_out0 ? "force_dbg" : "force");
+    const int unit = kXcds << s->xcd_run_log;  // the grid is rounded up to whole runs
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-    const int ablate = (g_ablate & 255) | (xcd_run_log() << 8);
-    Vec3<float> *out = (Vec3<float> *)(g_out0 ? g_out0 : s->b.force);
+    const int ablate = (s->dbg_ablate & 255) | (s->xcd_run_log << 8);
+    Vec3<float> *out = (Vec3<float> *)(s->dbg_out0 ? s->dbg_out0 : s->b.force);
     if (fast)
         hipLaunchKernelGGL((force_tuned_kernel<kTunedBS, kRowCap, kQueueF, true>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
@@ -516,20 +513,20 @@ int launch_force_tuned(Solver *s) {
 // Launches one pass `reps` times with parts of the kernel switched off and the results sent to
 // scratch arrays, so that the solver state is untouched.  Timing experiments only.
 int debug_time_pass(Solver *s, int which, int ablate, int reps) {
-    g_ablate = ablate;
+    s->dbg_ablate = ablate;
     int rc = FSA_OK;
     for (int k = 0; k < reps && rc == FSA_OK; k++) {
         if (which == 0) {
-            g_out0 = s->b.tmpIndex;
-            g_out1 = s->b.tmpHash;
+            s->dbg_out0 = s->b.tmpIndex;
+            s->dbg_out1 = s->b.tmpHash;
             rc = launch_density_tuned(s);
         } else {
-            g_out0 = s->b.v_star_alt;
+            s->dbg_out0 = s->b.v_star_alt;
             rc = launch_force_tuned(s);
         }
     }
-    g_ablate = 0;
-    g_out0 = g_out1 = nullptr;
+    s->dbg_ablate = 0;
+    s->dbg_out0 = s->dbg_out1 = nullptr;
     return rc;
 }
 

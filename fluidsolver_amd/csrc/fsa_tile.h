@@ -3,8 +3,6 @@
 // See fsa_sph_tuned.hip for the description of the scheme.
 #pragma once
 
-#include <cstdlib>
-
 #include "fsa_pair.h"
 
 namespace fsa {
@@ -255,14 +253,6 @@ __device__ __forceinline__ void group_d2(const float4 &X, const float4 &Y, const
 // 64 consecutive blocks go to one XCD instead of every eighth block (measured: 5 % on the force pass;
 // one contiguous eighth of the range per XCD is slower, the eighths differ too much in cost).
 constexpr int kXcds = 8;
-inline int xcd_run_log() {  // FSA_XCD_RUN_LOG overrides the run length (log2) for experiments
-    static const int v = [] {
-        const char *e = getenv("FSA_XCD_RUN_LOG");
-        const int x = e ? atoi(e) : 6;
-        return x < 0 ? 0 : (x > 12 ? 12 : x);
-    }();
-    return v;
-}
 __device__ __forceinline__ int xcd_block(int run_log) {
     const int x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
     return ((k >> run_log) * kXcds + x) * (1 << run_log) + (k & ((1 << run_log) - 1));

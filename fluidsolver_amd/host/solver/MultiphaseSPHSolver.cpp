@@ -280,6 +280,11 @@ void MultiphaseSPHSolver::Setup() {
         }
         want = run_mode;
     }
+    if ((want == DFSPH || want == IISPH) && std::getenv("FSA_RESUME")) {
+        // the text checkpoint carries neither the pressures nor the DFSPH factors these steps start from
+        std::fprintf(stderr, "FSA_RESUME: a text checkpoint can only be resumed by the SPH (WCSPH) step\n");
+        std::exit(EXIT_FAILURE);
+    }
     if (want == DFSPH) {
         SetupDFSPH();
         return;
@@ -353,25 +358,54 @@ void MultiphaseSPHSolver::LoadSimulationDataText(const char *filepath) {
         std::printf("error opening file\n");
         return;
     }
+    // The file is read into temporaries and checked as a whole before any solver state is touched: a truncated
+    // or hand-edited dump must end in "malformed checkpoint", not in a damaged heap.
+    std::fseek(fp, 0, SEEK_END);
+    const long file_bytes = std::ftell(fp);
+    std::fseek(fp, 0, SEEK_SET);
     int n = 0;
-    if (std::fscanf(fp, "%d\n", &n) != 1 || n < 0) {
+    // a particle line has at least 14 numbers of at least two characters each
+    if (std::fscanf(fp, "%d\n", &n) != 1 || n < 0 || (long)n > file_bytes / 28) {
         std::printf("malformed checkpoint\n");
         std::fclose(fp);
         return;
     }
-    ClearParticles();
+    struct Line {
+        cfloat3 pos, vel, v_star;
+        int type, group, id;
+        float mass;
+    };
+    std::vector<Line> lines((size_t)n);
+    vecf frac((size_t)n * maxtypenum);
+    std::vector<char> seen((size_t)n, 0);
     for (int k = 0; k < n; k++) {
-        const int i = AddDefaultParticle();
-        bool ok = std::fscanf(fp, "%f %f %f ", &pos[i].x, &pos[i].y, &pos[i].z) == 3;
-        ok = ok && std::fscanf(fp, "%f %f %f ", &vel[i].x, &vel[i].y, &vel[i].z) == 3;
-        ok = ok && std::fscanf(fp, "%d %d %f %d ", &type[i], &group[i], &mass[i], &unique_id[i]) == 4;
-        ok = ok && std::fscanf(fp, "%f %f %f ", &v_star[i].x, &v_star[i].y, &v_star[i].z) == 3;
-        for (int t = 0; ok && t < maxtypenum; t++) ok = std::fscanf(fp, "%f ", &vol_frac[(size_t)i * maxtypenum + t]) == 1;
+        Line &L = lines[k];
+        bool ok = std::fscanf(fp, "%f %f %f ", &L.pos.x, &L.pos.y, &L.pos.z) == 3;
+        ok = ok && std::fscanf(fp, "%f %f %f ", &L.vel.x, &L.vel.y, &L.vel.z) == 3;
+        ok = ok && std::fscanf(fp, "%d %d %f %d ", &L.type, &L.group, &L.mass, &L.id) == 4;
+        ok = ok && std::fscanf(fp, "%f %f %f ", &L.v_star.x, &L.v_star.y, &L.v_star.z) == 3;
+        for (int t = 0; ok && t < maxtypenum; t++) ok = std::fscanf(fp, "%f ", &frac[(size_t)k * maxtypenum + t]) == 1;
+        // ids index the per-identity tables: each of 0 .. n-1 exactly once
+        ok = ok && L.id >= 0 && L.id < n && !seen[L.id];
         if (!ok) {
             std::printf("malformed checkpoint at particle %d\n", k);
             std::fclose(fp);
             return;
         }
+        seen[L.id] = 1;
+    }
+    ClearParticles();
+    for (int k = 0; k < n; k++) {
+        const int i = AddDefaultParticle();
+        const Line &L = lines[k];
+        pos[i] = L.pos;
+        vel[i] = L.vel;
+        v_star[i] = L.v_star;
+        type[i] = L.type;
+        group[i] = L.group;
+        mass[i] = L.mass;
+        unique_id[i] = L.id;
+        for (int t = 0; t < maxtypenum; t++) vol_frac[(size_t)i * maxtypenum + t] = frac[(size_t)k * maxtypenum + t];
         // the dump does not carry the rest density: rebuild it as the setup does
         float density = 0.f;
         for (int t = 0; t < maxtypenum; t++) density += densArr[t] * vol_frac[(size_t)i * maxtypenum + t];

@@ -108,8 +108,14 @@ int fsa_derive_params(fsa_params *p, int precision, double spacing, double smoot
 /*
  * Replaces SetupDeviceBuffer (MultiphaseSPHSolver.cpp:871-977) +
  * CopyParam2Device (solver/sph_solver.cu:18-20).  `capacity` = maximum number
- * of particles; `device` = HIP device ordinal.  Allocates every device buffer
- * once; no later call allocates device memory.
+ * of particles; `device` = HIP device ordinal.  Allocates the device buffers of
+ * the WCSPH step for that capacity (about 480 bytes per particle in fp32, the
+ * recorded hits of kernel variant 3 among them) and 20 bytes per grid cell; a
+ * step allocates nothing.  Two things are allocated later, once, when first
+ * used: the neighbour lists of the IISPH / DFSPH steps (fsa_set_neighbour_lists;
+ * if that allocation fails the passes search instead) and the table of
+ * fsa_set_volume_fractions.  Read-back and upload calls use temporary staging
+ * buffers.
  */
 int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa_solver **out);
 int fsa_destroy(fsa_solver *s);
@@ -230,7 +236,7 @@ int fsa_step_dfsph(fsa_solver *s, int nsteps);
  */
 /* Volume fractions for EffectiveMass: typenum (1..10) fractions per particle, rows in the current device
  * order (n x typenum reals), and <DensityArray>.  Kept per particle identity until the next fsa_upload; this
- * call allocates the table (the only device allocation after fsa_create).  Synchronises. */
+ * call allocates the table (see fsa_create for what else is allocated after it).  Synchronises. */
 int fsa_set_volume_fractions(fsa_solver *s, int typenum, const double *dens_arr, const void *vfrac);
 /* EffectiveMass (solver/sph_solver.cu:288-298, kernel solver/sph_kernel_impl.cuh:1722-1755): mass =
  * rest density x spacing^3, rest density = sum of fraction x phase density, colour = the first three

@@ -73,3 +73,43 @@ def test_fused_step_row_table_large_rows():
     same(snapshot(a), snapshot(b))
     a.close()
     b.close()
+
+
+def test_rank_in_very_crowded_cells(orc32):
+    """the rank pass counts, per particle, the entries of its cell with a smaller source index: quadratic in the
+    cell's population.  Cells with 700 and 1500 particles (in shuffled upload order) must still come out in the
+    reference's stable order, from the staged calls and from fsa_step alike."""
+    from tests.util import oracle_pair
+    sc = scenes.dam_break(6, 6, 6, tank_x_factor=2.0, walls=False, boundary_mode=0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    crowd = np.concatenate([np.array([0.021, 0.021, 0.021], np.float32) + rng.uniform(0, 0.008, (700, 3)).astype(np.float32),
+                            np.array([0.041, 0.021, 0.031], np.float32) + rng.uniform(0, 0.008, (1500, 3)).astype(np.float32)])
+    m, n0 = len(crowd), len(sc["pos"])
+    out = {"params": sc["params"], "n_fluid": sc["n_fluid"] + m}
+    out["pos"] = np.concatenate([sc["pos"], crowd])
+    out["vel"] = np.concatenate([sc["vel"], np.zeros((m, 3), np.float32)])
+    out["normal"] = np.concatenate([sc["normal"], np.zeros((m, 3), np.float32)])
+    out["color"] = np.concatenate([sc["color"], np.ones((m, 4), np.float32)])
+    out["type"] = np.concatenate([sc["type"], np.zeros(m, np.int32)])
+    out["group"] = np.concatenate([sc["group"], np.zeros(m, np.int32)])
+    out["mass"] = np.concatenate([sc["mass"], np.full(m, sc["mass"][0], np.float32)])
+    out["restDensity"] = np.concatenate([sc["restDensity"], np.full(m, 1000, np.float32)])
+    out["uniqueId"] = rng.permutation(n0 + m).astype(np.int32)
+    perm = rng.permutation(n0 + m)
+    for k in ("pos", "vel", "normal", "color", "type", "group", "mass", "restDensity", "uniqueId"):
+        out[k] = np.ascontiguousarray(out[k][perm])
+    p_o, st = oracle_pair(orc32, out)
+    st.sort_particles(p_o)
+    counts = np.bincount(st["particleHash"][st["particleHash"] < 99999999])
+    assert counts.max() >= 1500
+    _, a = gpu_solver(out)
+    a.calc_hash()
+    a.sort_particle()
+    assert np.array_equal(a.get("particleIndex"), st["particleIndex"])
+    a.reorder()
+    assert np.array_equal(a.get("uniqueId"), st["uniqueId"])
+    _, b = gpu_solver(out)
+    b.sort_particles()  # the fused launches
+    assert np.array_equal(b.get("uniqueId"), st["uniqueId"])
+    assert np.array_equal(b.get("particleHash"), st["particleHash"])
+    a.close(); b.close(); st.close()

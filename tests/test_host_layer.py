@@ -193,6 +193,56 @@ def test_text_checkpoint_resume(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_corrupted_checkpoint_is_refused(tmp_path):
+    """ids outside 0 .. n-1, repeated ids, a particle count far beyond the file and a truncated file: each must end
+    in "malformed checkpoint" and leave the set-up scene running, not write through a bad index"""
+    exe = os.path.join(HOST, "bin", "particle_solver")
+    e = env_for(20)
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    e["FSA_DUMP_DIR"] = str(dump)
+    good = tmp_path / "good.bin"
+    subprocess.check_call([exe, "--frames", "2", "--keys", "b", "--save-final", str(good)], env=e,
+                          stdout=subprocess.DEVNULL, timeout=300)
+    lines = (dump / "002.txt").read_text().splitlines()
+    n = int(lines[0])
+
+    def with_id(k, new_id):
+        f = lines[k].split()
+        f[9] = str(new_id)
+        return " ".join(f)
+
+    cases = {
+        "negative id": [lines[0], with_id(1, -7)] + lines[2:],
+        "id beyond n": [lines[0], with_id(1, n + 1000000)] + lines[2:],
+        "repeated id": [lines[0], lines[1], with_id(2, lines[1].split()[9])] + lines[3:],
+        "count beyond file": [str(2000000000)] + lines[1:50],
+        "truncated": lines[: n // 2],
+    }
+    for name, text in cases.items():
+        bad = tmp_path / "bad.txt"
+        bad.write_text("\n".join(text) + "\n")
+        out = tmp_path / "out.bin"
+        r = subprocess.run([exe, "--frames", "2", "--save-final", str(out)], env=dict(e, FSA_RESUME=str(bad)),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-500:])
+        assert "malformed checkpoint" in r.stdout, name
+        # the run went on from the scene the set-up built
+        assert out.read_bytes() == good.read_bytes(), name
+
+
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
+@pytest.mark.parametrize("mode", ["IISPH", "DFSPH"])
+def test_resume_is_refused_in_modes_that_cannot_honour_it(tmp_path, mode):
+    exe = os.path.join(HOST, "bin", "particle_solver")
+    e = dict(env_for(20), FSA_RUN_MODE=mode, FSA_RESUME=str(tmp_path / "none.txt"))
+    r = subprocess.run([exe, "--frames", "1"], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "FSA_RESUME" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
 def test_headless_program_dfsph_mode(tmp_path):
     from fluidsolver_amd import capi
     frames = 6
