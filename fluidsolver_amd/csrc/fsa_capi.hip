@@ -86,6 +86,7 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.own_hi = 1 << 30;
     d.rows = nullptr;
     d.big = nullptr;
+    d.count = nullptr;
 }
 
 void make_dev_params(const fsa_params &h, DevParams<float> &d) { to_dev_params(h, d); }
@@ -536,12 +537,8 @@ int fsa_reorder_data_and_find_cell_start(fsa_solver *hs) {
 int fsa_sort_particles(fsa_solver *hs) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    if (s->slab) {  // z-slab solvers rank by order key
-        TRY(fsa_calc_hash(hs));
-        TRY(fsa_sort_particle(hs));
-        return fsa_reorder_data_and_find_cell_start(hs);
-    }
-    // the three stages in five launches (see fsa_step); same arrays, same bits
+    // the three stages in five launches (see fsa_step); same arrays, same bits (z-slab solvers: ties inside a cell
+    // by order key, and the new keys written, in the same rank pass)
     if (!s->hash_valid && !s->hash_ahead) TRY(launch_hash_fused(s, false));
     TRY(launch_sort_fused(s, true));
     s->cur = 1 - s->cur;
@@ -588,7 +585,7 @@ int fsa_step(fsa_solver *hs, int nsteps) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
     if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
-    if (s->slab) {  // z-slab solvers rank by order key: the staged launches
+    if (s->slab) {  // the particle set changes between integration and sort (exchange): no hash ahead of time
         for (int k = 0; k < nsteps; k++) {
             TRY(fsa_sort_particles(hs));
             TRY(launch_density(s));

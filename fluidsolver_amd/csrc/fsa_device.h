@@ -62,7 +62,15 @@ template <typename T> struct DevParams {
     // fp32 solvers: the row table of the tiled passes for the current sorted order (see fsa_tile.h), else null
     const int *rows;
     const int *big;   // [0] = number of blocks with large tiles, then their ids (fsa_tile.h); rebuilt with `rows`
+    // z-slab groups that run without host round trips: the number of particles lives in device memory (it changes
+    // with every exchange) and the kernels of the step read it from here instead of taking their argument, which is
+    // then only an upper bound the grid was sized for.  Null otherwise.
+    const int *count;
 };
+
+template <typename T> __device__ __forceinline__ int live_count(const DevParams<T> &P, int n) {
+    return P.count ? *P.count : n;
+}
 
 __device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, cons
                                                             int *__restrict__ cellCount,
                                                             int *__restrict__ undefBlockCount) {
     __shared__ int waveCount[kBlock / 64];
+    n = live_count(P, n);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i < n;
     T x = 0, y = 0, z = 0;
@@ -371,7 +372,11 @@ struct Scan2 {
     int *out[2];
     int n[2];
     int tiles[2];
+    const int *count;  // when set: n[1] = number of kBlock-blocks of *count particles (see DevParams::count)
 };
+__device__ __forceinline__ int scan2_n(const Scan2 &a, int k) {
+    return (k == 1 && a.count) ? (*a.count + kBlock - 1) / kBlock : a.n[k];
+}
 
 __global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(Scan2 a, int *__restrict__ tileSums,
                                                                  int *__restrict__ big) {
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void scan2_tile_sums_kernel(Scan2 a, int *_
     const int k = (int)blockIdx.x < a.tiles[0] ? 0 : 1;
     const int tile = (int)blockIdx.x - (k ? a.tiles[0] : 0);
     const int *in = a.in[k];
-    const int n = a.n[k];
+    const int n = scan2_n(a, k);
     const long long base = (long long)tile * kScanTile + (long long)threadIdx.x * kScanPerThread;
     int sum = 0;
     if (base + kScanPerThread <= n) {
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void scan2_apply_kernel(Scan2 a, const int 
     const int tile = (int)blockIdx.x - first;
     const int *in = a.in[k];
     int *out = a.out[k];
-    const int n = a.n[k];
+    const int n = scan2_n(a, k);
     int before = 0;
     for (int j = threadIdx.x; j < tile; j += kBlock) before += tileSums[first + j];
     int carry;
@@ -448,13 +453,15 @@ __global__ __launch_bounds__(kBlock) void scan2_apply_kernel(Scan2 a, const int 
 // scatter_kernel, and the first arrival of every cell also notes which blocks of kTunedBS sorted positions begin
 // and end inside its cell: the cell of a block's first and of its last particle (blockLo / blockHi), which the row
 // table needs, known here before the particles are in place.
-__global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, int num_cells, const int *__restrict__ hash,
+__global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, const int *__restrict__ count, int num_cells,
+                                                                const int *__restrict__ hash,
                                                                 const int *__restrict__ slot,
                                                                 const int *__restrict__ cellStart,
                                                                 const int *__restrict__ undefBlockStart,
                                                                 int *__restrict__ tmpIndex,
                                                                 int *__restrict__ tmpHash, int *__restrict__ blockLo,
                                                                 int *__restrict__ blockHi) {
+    if (count) n = *count;  // see DevParams::count
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned h = (unsigned)hash[i];
@@ -481,7 +488,9 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, int num_c
 // and the first 16 threads of each block write the row-table entry of the block of sorted positions they cover.
 // VSTAR_ALL = false: v_star only travels for particles that are not TYPE_FLUID (the integration rewrites it for
 // every fluid particle before anybody can read it).
-template <typename T, bool VSTAR_ALL>
+// BY_KEY (z-slab solvers, fsa_slab.hip): ties inside a cell are broken by the 64-bit order key each particle
+// carries instead of by the source index, and the key of the new order is written on the way.
+template <typename T, bool VSTAR_ALL, bool BY_KEY>
 __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
     DevParams<float> Pf, int n, const int *__restrict__ tmpIndex, const int *__restrict__ tmpHash,
     const int *__restrict__ cellStart, int *__restrict__ sortedIndex, int *__restrict__ sortedHash,
@@ -489,8 +498,11 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
     const int *__restrict__ uniqueIdIn, const Vec3<T> *__restrict__ vStarIn, Vec4<T> *__restrict__ posTypeOut,
     Vec4<T> *__restrict__ velMassOut, T *__restrict__ restDensityOut, int *__restrict__ uniqueIdOut,
     Vec3<T> *__restrict__ vStarOut, const int *__restrict__ blockLo, const int *__restrict__ blockHi,
-    int *__restrict__ table, int *__restrict__ big) {
+    int *__restrict__ table, int *__restrict__ big, const long long *__restrict__ keyIn,
+    long long *__restrict__ keyOut) {
     static_assert(kTunedBS == kBlock, "one row-table entry per block of this kernel");
+    n = live_count(Pf, n);
+    if ((int)blockIdx.x * kBlock >= n) return;
     const int sIdx = blockIdx.x * kBlock + threadIdx.x;
     if (table && threadIdx.x < 64) {  // row table (fp32 solvers), as block_rows_kernel
         const int blk = blockIdx.x, r = threadIdx.x & 15;
@@ -526,14 +538,35 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
     const int i = tmpIndex[sIdx];
     const unsigned h = (unsigned)tmpHash[sIdx];
     int p = sIdx;  // out-of-grid particles are already in stable order
+    int first = cellStart[Pf.num_cells];  // of the particle's cell (out of grid: of the tail)
     if (h != FSA_GRID_UNDEF) {
         const int a = cellStart[h], b = cellStart[h + 1];
         int r = 0;
-        for (int t = a; t < b; t++) r += (tmpIndex[t] < i) ? 1 : 0;
+        if (BY_KEY) {
+            const unsigned long long mine = (unsigned long long)keyIn[i];
+            for (int t = a; t < b; t++) {
+                const int j = tmpIndex[t];
+                const unsigned long long other = (unsigned long long)keyIn[j];
+                r += (other < mine || (other == mine && j < i)) ? 1 : 0;
+            }
+        } else {
+            for (int t = a; t < b; t++) r += (tmpIndex[t] < i) ? 1 : 0;
+        }
         p = a + r;
+        first = a;
     }
     sortedIndex[p] = i;
     sortedHash[p] = (int)h;
+    if (BY_KEY) {  // (global cell id << 32) | rank inside the cell; out of grid: (GRID_UNDEF << 32) | rank in the tail
+        unsigned long long hi = FSA_GRID_UNDEF;
+        if (h != FSA_GRID_UNDEF) {
+            const unsigned gx = (unsigned)Pf.gres[0];
+            const unsigned x = h % gx, t = h / gx;
+            const unsigned lz = t % (unsigned)Pf.nz, y = t / (unsigned)Pf.nz;
+            hi = ((unsigned long long)y * (unsigned)Pf.gres[2] + (lz + (unsigned)Pf.z0)) * gx + x;
+        }
+        keyOut[p] = (long long)((hi << 32) | (unsigned)(p - first));
+    }
     const Vec4<T> pt = posTypeIn[i];
     posTypeOut[p] = pt;
     velMassOut[p] = velMassIn[i];
@@ -548,7 +581,7 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
 static inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 int launch_hash_count(Solver *s) {
-    const int n = s->n, nb = blocks_for(n);
+    const int n = s->grid_n(), nb = blocks_for(n);
     if (!s->counts_clean) {
         ScopedTimer t(s, "clear_counts");
         FSA_HIP(hipMemsetAsync(s->b.cellCount, 0, (size_t)s->num_cells * sizeof(int), s->stream));
@@ -658,8 +691,9 @@ int launch_hash_fused(Solver *s, bool with_advect) {
 // fsa_sort_particle + fsa_reorder_data_and_find_cell_start of a single (not z-slab) solver in four launches;
 // hash / slot / cellCount must describe the current arrays.  Leaves cellCount zeroed.
 int launch_sort_fused(Solver *s, bool vstar_all) {
-    const int n = s->n, nb = blocks_for(n), C = s->num_cells;
+    const int n = s->grid_n(), nb = blocks_for(n), C = s->num_cells;
     Scan2 a;
+    a.count = s->pf.count;
     a.in[0] = s->b.cellCount;
     a.out[0] = s->b.cellStart;
     a.n[0] = C;
@@ -667,7 +701,7 @@ int launch_sort_fused(Solver *s, bool vstar_all) {
     a.in[1] = s->b.undefBlockCount;
     a.out[1] = s->b.undefBlockStart;
     a.n[1] = nb;
-    a.tiles[1] = n ? (nb + 1 + kScanTile - 1) / kScanTile : 0;
+    a.tiles[1] = n ? (nb + 1 + kScanTile - 1) / kScanTile : 0;  // with a device-side count: sized for the bound
     {
         ScopedTimer t(s, "scan_sums");
         hipLaunchKernelGGL(scan2_tile_sums_kernel, dim3(a.tiles[0] + a.tiles[1]), dim3(kBlock), 0, s->stream, a,
@@ -683,7 +717,7 @@ int launch_sort_fused(Solver *s, bool vstar_all) {
     if (n == 0) return FSA_OK;
     {
         ScopedTimer t(s, "scatter");
-        hipLaunchKernelGGL(scatter_bounds_kernel, dim3(nb), dim3(kBlock), 0, s->stream, n, C, s->b.hash, s->b.slot,
+        hipLaunchKernelGGL(scatter_bounds_kernel, dim3(nb), dim3(kBlock), 0, s->stream, n, s->pf.count, C, s->b.hash, s->b.slot,
                            s->b.cellStart, s->b.undefBlockStart, s->b.tmpIndex, s->b.tmpHash, s->b.blockLo,
                            s->b.blockHi);
     }
@@ -691,18 +725,20 @@ int launch_sort_fused(Solver *s, bool vstar_all) {
     {
         ScopedTimer t(s, "rank_reorder");
         const bool f32 = s->precision == FSA_PRECISION_F32;
-#define FSA_RR(T, T4, ALL)                                                                                           \
-    hipLaunchKernelGGL((rank_reorder_kernel<T, ALL>), dim3(nb), dim3(kBlock), 0, s->stream, s->pf, n, s->b.tmpIndex, \
-                       s->b.tmpHash, s->b.cellStart, s->b.sortedIndex, s->b.sortedHash,                              \
-                       (const T4 *)s->b.posType[in], (const T4 *)s->b.velMass[in], (const T *)s->b.restDensity[in],  \
-                       s->b.uniqueId[in], (const Vec3<T> *)s->b.v_star, (T4 *)s->b.posType[out],                     \
-                       (T4 *)s->b.velMass[out], (T *)s->b.restDensity[out], s->b.uniqueId[out],                      \
-                       (Vec3<T> *)s->b.v_star_alt, s->b.blockLo, s->b.blockHi, f32 ? s->b.blockRows : nullptr,       \
-                       s->b.bigBlocks)
-        if (f32) {
-            if (vstar_all) FSA_RR(float, float4, true); else FSA_RR(float, float4, false);
+#define FSA_RR(T, T4, ALL, KEY)                                                                                     \
+    hipLaunchKernelGGL((rank_reorder_kernel<T, ALL, KEY>), dim3(nb), dim3(kBlock), 0, s->stream, s->pf, n,          \
+                       s->b.tmpIndex, s->b.tmpHash, s->b.cellStart, s->b.sortedIndex, s->b.sortedHash,              \
+                       (const T4 *)s->b.posType[in], (const T4 *)s->b.velMass[in], (const T *)s->b.restDensity[in], \
+                       s->b.uniqueId[in], (const Vec3<T> *)s->b.v_star, (T4 *)s->b.posType[out],                    \
+                       (T4 *)s->b.velMass[out], (T *)s->b.restDensity[out], s->b.uniqueId[out],                     \
+                       (Vec3<T> *)s->b.v_star_alt, s->b.blockLo, s->b.blockHi, f32 ? s->b.blockRows : nullptr,      \
+                       s->b.bigBlocks, s->b.orderKey[in], s->b.orderKey[out])
+        if (s->slab) {
+            if (f32) FSA_RR(float, float4, false, true); else FSA_RR(double, double4, false, true);
+        } else if (f32) {
+            if (vstar_all) FSA_RR(float, float4, true, false); else FSA_RR(float, float4, false, false);
         } else {
-            if (vstar_all) FSA_RR(double, double4, true); else FSA_RR(double, double4, false);
+            if (vstar_all) FSA_RR(double, double4, true, false); else FSA_RR(double, double4, false, false);
         }
 #undef FSA_RR
         FSA_HIP(hipGetLastError());

@@ -117,6 +117,8 @@ struct Solver {
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
     int variant = 3;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32,
                       // 3 as 2 with one neighbour search per step (fsa_sph_fast.hip; same bits as 2)
+    // number of particles the launch grids must cover: n, or the capacity while n lives on the device
+    int grid_n() const { return pf.count ? capacity : n; }
     int xcd_run_log = 6;  // log2 of the run of consecutive blocks handed to one XCD (fsa_tile.h); FSA_XCD_RUN_LOG,
                           // read once by fsa_create, overrides it for experiments
     // timing experiments (debug_time_pass): parts of the tuned passes switched off, results to scratch arrays

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void advect_kernel(DevParams<T> P, int n, V
                                                         const Vec3<T> *__restrict__ force,
                                                         Vec3<T> *__restrict__ v_star) {
     const int index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n) return;
+    if (index >= live_count(P, n)) return;
     Vec4<T> p = posType[index];
     if (!advect_moves(P, unpack_int(p.w))) return;
     Vec4<T> v = velMass[index];
@@ -219,6 +219,8 @@ int launch_density(Solver *s) {
     if (s->n == 0) return FSA_OK;
     // the dedicated tuned density kernel has no TYPE_RIGID term; scenes with rigid particles take the
     // tiled pass with the exact arithmetic (slab runs keep the generic kernel: it knows the halo rules)
+    if (s->pf.count && !(s->precision == FSA_PRECISION_F32 && s->variant == 3 && !s->has_rigid))
+        return fail(FSA_ERR_INVALID, "a device-side particle count needs the fp32 variant-3 kernels and no TYPE_RIGID particles");
     if (s->precision == FSA_PRECISION_F32 && s->variant >= 1 && !s->has_rigid) return launch_density_tuned(s);
     if (s->precision == FSA_PRECISION_F32 && s->variant >= 1 && !s->slab) return launch_density_rigid_tuned(s);
     ScopedTimer t(s, "density");
@@ -239,12 +241,12 @@ int launch_force(Solver *s) {
 }
 
 int launch_advect(Solver *s) {
-    if (s->n == 0) return FSA_OK;
+    if (s->grid_n() == 0) return FSA_OK;
     ScopedTimer t(s, "advect");
     s->lists_valid = false;  // positions move
     s->hits_valid = false;
     const int c = s->cur;
-    FSA_DISPATCH(advect_kernel, s->n, P, s->n, (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
+    FSA_DISPATCH(advect_kernel, s->grid_n(), P, s->grid_n(), (Vec4<T> *)s->b.posType[c], (Vec4<T> *)s->b.velMass[c],
                  (const Vec3<T> *)s->b.force, (Vec3<T> *)s->b.v_star);
     return FSA_OK;
 }

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
     const int tid = threadIdx.x;
     const int dbg = run_log >> 8;
     run_log &= 255;
+    n = live_count(P, n);
     const int blk = xcd_block(run_log);
     const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
     const int dbg = run_log >> 8;
     run_log &= 255;
     const int quorum = (dbg >> 4) ? (dbg >> 4) : 40;
+    n = live_count(P, n);
     const int blk = xcd_block(run_log);
     const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
@@ -567,13 +569,13 @@ constexpr int kQueueD = 10;  // density queue: 4-byte slots (with the tile: 19.6
 
 static inline int tiled_grid(const Solver *s, int run_log) {
     const int unit = kXcds << run_log;  // the grid is rounded up to whole runs
-    return ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
+    return ((s->grid_n() + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
 }
 
 template <bool EVAL> static int launch_density_record(Solver *s) {
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
     hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, run_log)),
-                       dim3(kTunedBS), 0, s->stream, s->pf, s->n, (const float4 *)s->b.posType[c],
+                       dim3(kTunedBS), 0, s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c],
                        (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
                        s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, (float *)s->b.density,
                        (float *)s->b.pressure, (float2 *)s->b.pd, run_log);
@@ -583,7 +585,7 @@ template <bool EVAL> static int launch_density_record(Solver *s) {
 }
 
 int launch_density_fast(Solver *s) {
-    if (s->n == 0) return FSA_OK;
+    if (s->grid_n() == 0) return FSA_OK;
     ScopedTimer t(s, "density");
     int rc = launch_density_record<true>(s);
     if (rc) return rc;
@@ -594,7 +596,7 @@ int launch_density_fast(Solver *s) {
 
 // needs pd[] in the fast layout (the caller sees to that)
 int launch_force_fast(Solver *s) {
-    if (s->n == 0) return FSA_OK;
+    if (s->grid_n() == 0) return FSA_OK;
     if (!s->hits_valid) {
         ScopedTimer t(s, "record_hits");
         int rc = launch_density_record<false>(s);
@@ -603,7 +605,7 @@ int launch_force_fast(Solver *s) {
     ScopedTimer t(s, "force");
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
     hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, run_log)), dim3(kTunedBS), 0,
-                       s->stream, s->pf, s->n, (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
+                       s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                        (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
                        s->b.hitCount, (Vec3<float> *)s->b.force, run_log);
     FSA_HIP(hipGetLastError());

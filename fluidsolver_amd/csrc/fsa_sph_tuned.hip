@@ -446,7 +446,7 @@ constexpr int kQueueD = 10;   // density: 4-byte slots (with the tile: 19.9 KB, 
 constexpr int kQueueF = 48;   // force: 2-byte slots
 
 int launch_density_tuned(Solver *s) {
-    if (s->n == 0) return FSA_OK;
+    if (s->grid_n() == 0) return FSA_OK;
     if (s->variant == 3 && !s->dbg_out0) return launch_density_fast(s);
     ScopedTimer t(s, s->dbg_out0 ? "density_dbg" : "density");
     const int c = s->cur;
@@ -474,7 +474,7 @@ int launch_density_tuned(Solver *s) {
 }
 
 int launch_force_tuned(Solver *s) {
-    if (s->n == 0) return FSA_OK;
+    if (s->grid_n() == 0) return FSA_OK;
     const int c = s->cur;
     const bool fast = s->variant >= 2;
     if (!(s->pd_valid && s->pd_fast == fast)) {
