@@ -31,6 +31,8 @@ EXPORTS = (
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant", "fsa_set_neighbour_lists",
     "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned", "fsa_slab_export_owned",
     "fsa_set_scene_has_rigid", "fsa_sort_particle_static",
+    "fsa_slab_group_create_local", "fsa_slab_group_unique_id", "fsa_slab_group_create_rccl", "fsa_slab_group_step",
+    "fsa_slab_group_sync", "fsa_slab_group_rccl_loopback", "fsa_slab_group_destroy",
     "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
     "fsa_solve_divergence_stiff", "fsa_apply_pstiff", "fsa_update_position", "fsa_update_velocities",
     "fsa_correct_density_error", "fsa_correct_divergence_error", "fsa_setup_dfsph", "fsa_step_dfsph",
@@ -65,6 +67,14 @@ class Params(C.Structure):
     def num_cells(self) -> int:
         nz = self.slab_nz if self.slab_nz > 0 else self.gridres[2]
         return self.gridres[0] * self.gridres[1] * nz
+
+
+SLAB_GROUP_ID_BYTES = 128
+
+
+class SlabGroupStats(C.Structure):
+    _fields_ = [("steps", C.c_longlong), ("particles", C.c_longlong), ("max_particles", C.c_longlong),
+                ("lost", C.c_longlong), ("records_sent", C.c_longlong), ("error_bits", C.c_int)]
 
 
 class KernelTime(C.Structure):
@@ -137,6 +147,15 @@ def load() -> C.CDLL:
         "fsa_slab_set_owned": [H, C.POINTER(C.c_int)],
         "fsa_slab_export_owned": [H, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)],
         "fsa_set_scene_has_rigid": [H, C.c_int],
+        "fsa_slab_group_create_local": [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p)],
+        "fsa_slab_group_unique_id": [C.c_char_p],
+        "fsa_slab_group_create_rccl": [H, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)],
+        "fsa_slab_group_step": [H, C.c_int],
+        "fsa_slab_group_sync": [H, C.POINTER(SlabGroupStats)],
+        "fsa_slab_group_rccl_loopback": [H, C.c_void_p, C.c_void_p, C.c_size_t],
+        "fsa_slab_group_destroy": [H],
         "fsa_sort_particle_static": [P, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
         "fsa_compute_density_alpha": [H], "fsa_compute_non_pressure_force": [H], "fsa_solve_density_stiff": [H],
         "fsa_solve_divergence_stiff": [H], "fsa_apply_pstiff": [H], "fsa_update_position": [H],
@@ -513,3 +532,57 @@ class GridSolver:
         it, r = C.c_int(), C.c_double()
         check(self.lib.fsa_grid_solve(self._h, int(maxiter), C.byref(it), C.byref(r)))
         return it.value, r.value
+
+
+class SlabGroup:
+    """fsa_slab_group: the z-slab step of several solvers without host round trips (see the header)."""
+
+    def __init__(self, handle, solvers):
+        self.lib = load()
+        self._h = handle
+        self.solvers = solvers  # kept alive
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(SLAB_GROUP_ID_BYTES)
+        check(load().fsa_slab_group_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def local(cls, solvers, cuts, halo, record_cap):
+        lib = load()
+        hs = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+        h = C.c_void_p()
+        check(lib.fsa_slab_group_create_local(len(solvers), hs, (C.c_int * len(cuts))(*cuts), int(halo),
+                                              int(record_cap), C.byref(h)))
+        return cls(h, list(solvers))
+
+    @classmethod
+    def rccl(cls, solver, rank, world, uid: bytes, cuts, halo, record_cap):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.fsa_slab_group_create_rccl(solver._h, int(rank), int(world), uid, (C.c_int * len(cuts))(*cuts),
+                                             int(halo), int(record_cap), C.byref(h)))
+        return cls(h, [solver])
+
+    def step(self, nsteps=1):
+        check(self.lib.fsa_slab_group_step(self._h, int(nsteps)))
+
+    def sync(self) -> SlabGroupStats:
+        st = SlabGroupStats()
+        check(self.lib.fsa_slab_group_sync(self._h, C.byref(st)))
+        return st
+
+    def rccl_loopback(self, src_ptr, dst_ptr, nbytes):
+        check(self.lib.fsa_slab_group_rccl_loopback(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), int(nbytes)))
+
+    def close(self):
+        if self._h:
+            self.lib.fsa_slab_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -119,7 +119,7 @@ static void free_all(Solver *s) {
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
                     b.gridCellEnd, b.blockRows, b.bigBlocks, b.blockLo, b.blockHi, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
-                    b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters};
+                    b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters, b.slabVars};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &t : s->launches) {
@@ -174,10 +174,25 @@ static void invalidate_order(Solver *s) {
 
 using namespace fsa;
 
+// A solver in a slab group keeps its particle count on the device; an entry point that needs it on the host
+// waits for the queued steps first.
+static int refresh_count(Solver *s) {
+    if (!s->count_stale) return FSA_OK;
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    int vars[kVarCount];
+    FSA_HIP(hipMemcpy(vars, s->b.slabVars, sizeof(vars), hipMemcpyDeviceToHost));
+    s->n = vars[kVarN];
+    s->count_stale = false;
+    if (vars[kVarError])
+        return fail(FSA_ERR_CAPACITY, "slab group: a count outgrew its buffer (bits %d); the state is invalid", vars[kVarError]);
+    return FSA_OK;
+}
+
 #define NEED(s)                                                   \
     do {                                                          \
         if (!(s)) return fail(FSA_ERR_INVALID, "solver is NULL"); \
         int _rc = activate(s);                                    \
+        if (!_rc) _rc = refresh_count(s);                         \
         if (_rc) return _rc;                                      \
     } while (0)
 #define TRY(expr)          \
@@ -324,6 +339,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
         ALLOC(b.orderKey[0], N * sizeof(long long), true);
         ALLOC(b.orderKey[1], N * sizeof(long long), true);
         ALLOC(b.slabCounters, 8 * sizeof(int), true);
+        ALLOC(b.slabVars, 16 * sizeof(int), true);
     }
 #undef ALLOC
     if (rc != FSA_OK) {
@@ -475,6 +491,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
 int fsa_num_particles(fsa_solver *hs, int *n) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     if (!s || !n) return fail(FSA_ERR_INVALID, "NULL argument");
+    NEED(s);  // in a slab group the count comes from the device
     *n = s->n;
     return FSA_OK;
 }

@@ -1,0 +1,421 @@
+// z-slab groups: the step of a scene cut into z-slabs (fsa_slab.hip), run for all slabs of this process -- or for
+// this process's slab, with the neighbours in other processes -- without a host round trip per step.
+//
+// The reference steps one device from one host thread (MultiphaseSPHSolver::Step,
+// solver/MultiphaseSPHSolver.cpp:199-217 under /root/reference/particle_solver).  What a slab step adds is the
+// exchange between integration and sort, and the host must not wait for it: the particle count of every slab
+// lives in device memory (DevParams::count), the pack and unpack kernels keep it and the message counts up to
+// date there, and launch grids are sized for the solver's capacity.
+//
+//   pack       particles owned at the last sort are sorted into stay / send left / send right (fsa_slab.hip); a
+//              one-thread kernel turns the atomic counters into the new particle count and the message headers;
+//   transport  LOCAL: all slabs belong to solvers of this process (on one GPU or several): the send buffer is
+//              copied into the neighbour's receive buffer on the sender's stream, events order it against the
+//              neighbour's unpack of this step and of the step before;
+//              RCCL: one slab per process: ncclSend / ncclRecv to both z-neighbours in one group call on the
+//              solver's stream (xGMI between the GPUs of a node);
+//   unpack     records of both receive buffers are appended, the count is raised;
+//   then the ordinary hash -> sort -> density -> force -> integration of the solver.
+//
+// Message sizes.  A send or copy needs its size on the host when it is queued, and the host does not know this
+// step's counts.  Both ends therefore size the message of step k from the count of step k - kLag, which each of
+// them has by then without waiting (the sender's own count, and the header the receiver got, both mirrored into
+// pinned host memory by the one-thread kernels and fenced by an event), plus head room; the actual count rides
+// in the buffer's header slot.  The first kLag steps send whole buffers.  A count that outgrows its message is cut
+// and flagged on the device; fsa_slab_group_sync reports it as an error (the run is then invalid: re-create the
+// group with more head room).
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fsa_solver.h"
+
+namespace fsa {
+
+constexpr int kLag = 3;    // steps between a count and the message size derived from it
+constexpr int kRing = 8;   // mirror slots (> kLag)
+constexpr int kMirrorInts = 8;
+
+struct Member {
+    Solver *s = nullptr;
+    int rank = 0;
+    int own[2] = {0, 0}, held[2] = {0, 0}, left[2] = {0, 0}, right[2] = {0, 0};
+    bool has_left = false, has_right = false;
+    char *send[2] = {nullptr, nullptr};  // [0] to the left neighbour, [1] to the right; header slot first
+    char *recv[2] = {nullptr, nullptr};  // [0] from the left neighbour, [1] from the right
+    int *mirror = nullptr;               // pinned host memory: kRing x kMirrorInts
+    hipEvent_t ev_pack[kRing] = {}, ev_unpack[kRing] = {}, ev_sent[2] = {};
+    int size_out[2] = {0, 0};            // records this step's messages take
+};
+
+struct Group {
+    int kind = 0;  // 0 LOCAL, 1 RCCL
+    int world = 0, halo = 0, record_cap = 0, rb = 0;
+    std::vector<int> cuts;
+    std::vector<Member> m;
+    ncclComm_t comm = nullptr;
+    long long step = 0;  // steps queued since the group was made
+    long long sent = 0;  // records sent by this process's members, as far as the host has seen the counts
+};
+
+static int next_size(int count, int cap) {
+    const long long v = (long long)count + count / 8 + 4096;
+    return (int)std::min<long long>(v, cap);
+}
+
+#define FSA_NCCL(expr)                                                                                       \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess)                                                                               \
+            return ::fsa::fail(FSA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, \
+                               __LINE__);                                                                    \
+    } while (0)
+
+static void held_of(const Group &g, int r, int out[2]) {
+    if (r < 0 || r >= g.world) {
+        out[0] = out[1] = 0;
+        return;
+    }
+    const int gz = g.cuts.back();
+    out[0] = std::max(g.cuts[r] - g.halo, 0);
+    out[1] = std::min(g.cuts[r + 1] + g.halo, gz);
+}
+
+static void free_member(Member &mb) {
+    if (mb.s) {
+        (void)hipSetDevice(mb.s->device);
+        (void)hipStreamSynchronize(mb.s->stream);
+        // the solver goes back to a host-side count
+        if (mb.s->pf.count) {
+            int n = mb.s->n;
+            if (hipMemcpy(&n, mb.s->b.slabVars + kVarN, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) mb.s->n = n;
+            mb.s->pf.count = mb.s->pd.count = nullptr;
+            mb.s->count_stale = false;
+        }
+    }
+    for (int d = 0; d < 2; d++) {
+        if (mb.send[d]) (void)hipFree(mb.send[d]);
+        if (mb.recv[d]) (void)hipFree(mb.recv[d]);
+        if (mb.ev_sent[d]) (void)hipEventDestroy(mb.ev_sent[d]);
+    }
+    for (int k = 0; k < kRing; k++) {
+        if (mb.ev_pack[k]) (void)hipEventDestroy(mb.ev_pack[k]);
+        if (mb.ev_unpack[k]) (void)hipEventDestroy(mb.ev_unpack[k]);
+    }
+    if (mb.mirror) (void)hipHostFree(mb.mirror);
+}
+
+static int setup_member(Group &g, Member &mb, Solver *s, int rank) {
+    if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
+    if (!s->slab) return fail(FSA_ERR_INVALID, "a slab group needs solvers created with slab_nz > 0");
+    if (s->precision != FSA_PRECISION_F32 || s->variant != 3 || s->has_rigid)
+        return fail(FSA_ERR_INVALID, "a slab group needs fp32 solvers on kernel variant 3 and a scene without TYPE_RIGID "
+                                     "particles (the kernels that take the particle count from device memory)");
+    mb.s = s;
+    mb.rank = rank;
+    mb.own[0] = g.cuts[rank];
+    mb.own[1] = g.cuts[rank + 1];
+    held_of(g, rank, mb.held);
+    held_of(g, rank - 1, mb.left);
+    held_of(g, rank + 1, mb.right);
+    mb.has_left = rank > 0;
+    mb.has_right = rank + 1 < g.world;
+    if (mb.held[0] != s->pf.z0 || mb.held[1] != s->pf.z0 + s->pf.nz)
+        return fail(FSA_ERR_INVALID, "rank %d: the solver holds layers [%d, %d), the cuts ask for [%d, %d)", rank, s->pf.z0,
+                    s->pf.z0 + s->pf.nz, mb.held[0], mb.held[1]);
+    FSA_HIP(hipSetDevice(s->device));
+    const size_t bytes = (size_t)(g.record_cap + 1) * g.rb;
+    for (int d = 0; d < 2; d++) {
+        if (d == 0 ? !mb.has_left : !mb.has_right) continue;
+        FSA_HIP(hipMalloc((void **)&mb.send[d], bytes));
+        FSA_HIP(hipMalloc((void **)&mb.recv[d], bytes));
+        FSA_HIP(hipMemset(mb.send[d], 0, g.rb));
+        FSA_HIP(hipMemset(mb.recv[d], 0, g.rb));
+        FSA_HIP(hipEventCreateWithFlags(&mb.ev_sent[d], hipEventDisableTiming));
+    }
+    for (int k = 0; k < kRing; k++) {
+        FSA_HIP(hipEventCreateWithFlags(&mb.ev_pack[k], hipEventDisableTiming));
+        FSA_HIP(hipEventCreateWithFlags(&mb.ev_unpack[k], hipEventDisableTiming));
+    }
+    FSA_HIP(hipHostMalloc((void **)&mb.mirror, sizeof(int) * kRing * kMirrorInts, hipHostMallocDefault));
+    std::memset(mb.mirror, 0, sizeof(int) * kRing * kMirrorInts);
+    // from here on the count lives on the device
+    FSA_HIP(hipStreamSynchronize(s->stream));
+    int vars[16] = {0};
+    vars[kVarN] = s->n;
+    FSA_HIP(hipMemcpy(s->b.slabVars, vars, sizeof(vars), hipMemcpyHostToDevice));
+    FSA_HIP(hipMemset(s->b.slabCounters, 0, 8 * sizeof(int)));
+    FSA_HIP(hipDeviceSynchronize());
+    s->pf.count = s->pd.count = s->b.slabVars + kVarN;
+    s->pf.own_lo = s->pd.own_lo = mb.own[0];
+    s->pf.own_hi = s->pd.own_hi = mb.own[1];
+    return FSA_OK;
+}
+
+// Sizes of this step's two outgoing messages of a member, from its own counts of kLag steps ago.
+static int outgoing_sizes(Group &g, Member &mb) {
+    for (int d = 0; d < 2; d++) mb.size_out[d] = g.record_cap;
+    if (g.step >= kLag) {
+        const int slot = (int)((g.step - kLag) % kRing);
+        FSA_HIP(hipEventSynchronize(mb.ev_pack[slot]));  // long done: no wait in steady state
+        const int *mi = mb.mirror + slot * kMirrorInts;
+        for (int d = 0; d < 2; d++) mb.size_out[d] = next_size(mi[d], g.record_cap);
+        g.sent += (long long)mi[0] + mi[1];
+    }
+    return FSA_OK;
+}
+
+// RCCL: the sizes of the two incoming messages, from the headers received kLag steps ago.
+static int incoming_sizes(Group &g, Member &mb, int size_in[2]) {
+    size_in[0] = size_in[1] = g.record_cap;
+    if (g.step >= kLag) {
+        const int slot = (int)((g.step - kLag) % kRing);
+        FSA_HIP(hipEventSynchronize(mb.ev_unpack[slot]));
+        const int *mi = mb.mirror + slot * kMirrorInts;
+        for (int d = 0; d < 2; d++) size_in[d] = next_size(mi[4 + d], g.record_cap);
+    }
+    return FSA_OK;
+}
+
+static int local_step(Solver *s) {
+    int rc = launch_hash_count(s);
+    if (!rc) rc = launch_sort_fused(s, false);
+    if (rc) return rc;
+    s->cur = 1 - s->cur;
+    s->hash_valid = s->hash_ahead = false;
+    s->sorted_valid = s->owned_from_sort = s->count_valid = true;
+    s->pd_valid = s->lists_valid = s->hits_valid = false;
+    s->perm_valid = s->index_table_valid = s->ref_cells_valid = false;
+    rc = launch_density(s);
+    if (!rc) rc = launch_force(s);
+    if (!rc) rc = launch_advect(s);
+    s->sorted_valid = false;  // positions moved
+    return rc;
+}
+
+static int group_step(Group &g) {
+    const int slot = (int)(g.step % kRing), prev = (int)((g.step + kRing - 1) % kRing);
+    // ---- pack -------------------------------------------------------------------------------------------------
+    for (Member &mb : g.m) {
+        Solver *s = mb.s;
+        FSA_HIP(hipSetDevice(s->device));
+        int rc = outgoing_sizes(g, mb);
+        if (rc) return rc;
+        rc = launch_slab_pack_dev(s, mb.own, mb.held, mb.left, mb.right, mb.send[0], mb.size_out[0], mb.send[1],
+                                  mb.size_out[1], mb.mirror + slot * kMirrorInts);
+        if (rc) return rc;
+        FSA_HIP(hipEventRecord(mb.ev_pack[slot], s->stream));
+        s->cur = 1 - s->cur;  // the particles that stay went to the other copy
+        s->hash_valid = s->hash_ahead = s->perm_valid = s->sorted_valid = s->count_valid = false;
+        s->owned_from_sort = false;
+        s->count_stale = true;
+    }
+    // ---- transport ----------------------------------------------------------------------------------------------
+    int size_in[2] = {0, 0};
+    if (g.kind == 0) {
+        for (Member &mb : g.m) {
+            Solver *s = mb.s;
+            FSA_HIP(hipSetDevice(s->device));
+            for (int d = 0; d < 2; d++) {
+                if (!mb.send[d]) continue;
+                Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
+                // the neighbour must be through with what it received in the step before
+                if (g.step > 0) FSA_HIP(hipStreamWaitEvent(s->stream, peer.ev_unpack[prev], 0));
+                const size_t bytes = (size_t)(1 + mb.size_out[d]) * g.rb;
+                char *dst = peer.recv[1 - d];
+                if (peer.s->device == s->device)
+                    FSA_HIP(hipMemcpyAsync(dst, mb.send[d], bytes, hipMemcpyDeviceToDevice, s->stream));
+                else
+                    FSA_HIP(hipMemcpyPeerAsync(dst, peer.s->device, mb.send[d], s->device, bytes, s->stream));
+                FSA_HIP(hipEventRecord(mb.ev_sent[d], s->stream));
+            }
+        }
+    } else {
+        Member &mb = g.m[0];
+        Solver *s = mb.s;
+        int rc = incoming_sizes(g, mb, size_in);
+        if (rc) return rc;
+        FSA_NCCL(ncclGroupStart());
+        for (int d = 0; d < 2; d++) {
+            if (!mb.send[d]) continue;
+            const int peer = mb.rank + (d == 0 ? -1 : 1);
+            FSA_NCCL(ncclSend(mb.send[d], (size_t)(1 + mb.size_out[d]) * g.rb, ncclChar, peer, g.comm, s->stream));
+            FSA_NCCL(ncclRecv(mb.recv[d], (size_t)(1 + size_in[d]) * g.rb, ncclChar, peer, g.comm, s->stream));
+        }
+        FSA_NCCL(ncclGroupEnd());
+    }
+    // ---- unpack and the solver's own step ---------------------------------------------------------------------
+    for (Member &mb : g.m) {
+        Solver *s = mb.s;
+        FSA_HIP(hipSetDevice(s->device));
+        int bound[2] = {0, 0};
+        for (int d = 0; d < 2; d++) {
+            if (!mb.recv[d]) continue;
+            if (g.kind == 0) {
+                Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
+                FSA_HIP(hipStreamWaitEvent(s->stream, peer.ev_sent[1 - d], 0));
+                bound[d] = peer.size_out[1 - d];
+            } else {
+                bound[d] = size_in[d];
+            }
+        }
+        int rc = launch_slab_unpack_dev(s, mb.recv[0], bound[0], mb.recv[1], bound[1], mb.mirror + slot * kMirrorInts);
+        if (rc) return rc;
+        FSA_HIP(hipEventRecord(mb.ev_unpack[slot], s->stream));
+        rc = local_step(s);
+        if (rc) return rc;
+    }
+    g.step++;
+    return FSA_OK;
+}
+
+}  // namespace fsa
+
+using namespace fsa;
+
+extern "C" {
+
+int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts, int halo, int record_cap,
+                                fsa_slab_group **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (world < 1 || !solvers || !cuts || halo < 1 || record_cap < 0) return fail(FSA_ERR_INVALID, "bad argument");
+    for (int r = 0; r < world; r++)
+        if (cuts[r + 1] - cuts[r] < halo + 1)
+            return fail(FSA_ERR_INVALID, "slab %d has %d layers, fewer than halo + 1 = %d", r, cuts[r + 1] - cuts[r], halo + 1);
+    Group *g = new (std::nothrow) Group();
+    if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
+    g->kind = 0;
+    g->world = world;
+    g->halo = halo;
+    g->record_cap = record_cap;
+    g->cuts.assign(cuts, cuts + world + 1);
+    g->rb = solvers[0] ? slab_record_bytes(reinterpret_cast<Solver *>(solvers[0])) : 48;
+    g->m.resize(world);
+    for (int r = 0; r < world; r++) {
+        int rc = setup_member(*g, g->m[r], reinterpret_cast<Solver *>(solvers[r]), r);
+        if (rc) {
+            for (Member &mb : g->m) free_member(mb);
+            delete g;
+            return rc;
+        }
+    }
+    *out = reinterpret_cast<fsa_slab_group *>(g);
+    return FSA_OK;
+}
+
+int fsa_slab_group_unique_id(char id[FSA_SLAB_GROUP_ID_BYTES]) {
+    if (!id) return fail(FSA_ERR_INVALID, "id is NULL");
+    static_assert(sizeof(ncclUniqueId) <= FSA_SLAB_GROUP_ID_BYTES, "id buffer too small");
+    ncclUniqueId u;
+    FSA_NCCL(ncclGetUniqueId(&u));
+    std::memset(id, 0, FSA_SLAB_GROUP_ID_BYTES);
+    std::memcpy(id, &u, sizeof(u));
+    return FSA_OK;
+}
+
+int fsa_slab_group_create_rccl(fsa_solver *solver, int rank, int world, const char id[FSA_SLAB_GROUP_ID_BYTES],
+                               const int *cuts, int halo, int record_cap, fsa_slab_group **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !solver || !cuts || !id || halo < 1 || record_cap < 0)
+        return fail(FSA_ERR_INVALID, "bad argument");
+    for (int r = 0; r < world; r++)
+        if (cuts[r + 1] - cuts[r] < halo + 1)
+            return fail(FSA_ERR_INVALID, "slab %d has %d layers, fewer than halo + 1 = %d", r, cuts[r + 1] - cuts[r], halo + 1);
+    Group *g = new (std::nothrow) Group();
+    if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
+    g->kind = 1;
+    g->world = world;
+    g->halo = halo;
+    g->record_cap = record_cap;
+    g->cuts.assign(cuts, cuts + world + 1);
+    Solver *s = reinterpret_cast<Solver *>(solver);
+    g->rb = slab_record_bytes(s);
+    g->m.resize(1);
+    int rc = setup_member(*g, g->m[0], s, rank);
+    if (!rc) {
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof(u));
+        ncclResult_t r = ncclCommInitRank(&g->comm, world, u, rank);
+        if (r != ncclSuccess) rc = fail(FSA_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    }
+    if (rc) {
+        free_member(g->m[0]);
+        delete g;
+        return rc;
+    }
+    *out = reinterpret_cast<fsa_slab_group *>(g);
+    return FSA_OK;
+}
+
+int fsa_slab_group_step(fsa_slab_group *hg, int nsteps) {
+    Group *g = reinterpret_cast<Group *>(hg);
+    if (!g) return fail(FSA_ERR_INVALID, "group is NULL");
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    for (int k = 0; k < nsteps; k++) {
+        int rc = group_step(*g);
+        if (rc) return rc;
+    }
+    return FSA_OK;
+}
+
+int fsa_slab_group_sync(fsa_slab_group *hg, fsa_slab_group_stats *st) {
+    Group *g = reinterpret_cast<Group *>(hg);
+    if (!g) return fail(FSA_ERR_INVALID, "group is NULL");
+    long long lost = 0, particles = 0, max_particles = 0;
+    int error = 0;
+    for (Member &mb : g->m) {
+        Solver *s = mb.s;
+        FSA_HIP(hipSetDevice(s->device));
+        FSA_HIP(hipStreamSynchronize(s->stream));
+        int vars[8];
+        FSA_HIP(hipMemcpy(vars, s->b.slabVars, sizeof(vars), hipMemcpyDeviceToHost));
+        s->n = vars[kVarN];
+        s->count_stale = false;
+        lost += vars[kVarLost];
+        error |= vars[kVarError];
+        particles += vars[kVarN];
+        max_particles = std::max<long long>(max_particles, vars[kVarN]);
+    }
+    if (st) {
+        st->steps = g->step;
+        st->particles = particles;
+        st->max_particles = max_particles;
+        st->lost = lost;
+        st->records_sent = g->sent;
+        st->error_bits = error;
+    }
+    if (error)
+        return fail(FSA_ERR_CAPACITY, "slab group: a count outgrew its buffer (bits %d: 1 solver capacity, 2 / 4 message to the "
+                                      "left / right, 8 / 16 message from the left / right); the state is invalid", error);
+    return FSA_OK;
+}
+
+int fsa_slab_group_rccl_loopback(fsa_slab_group *hg, const void *d_src, void *d_dst, size_t bytes) {
+    Group *g = reinterpret_cast<Group *>(hg);
+    if (!g || g->kind != 1 || !g->comm) return fail(FSA_ERR_INVALID, "needs a group made by fsa_slab_group_create_rccl");
+    if (bytes && (!d_src || !d_dst)) return fail(FSA_ERR_INVALID, "NULL buffer");
+    Member &mb = g->m[0];
+    FSA_HIP(hipSetDevice(mb.s->device));
+    FSA_NCCL(ncclGroupStart());
+    FSA_NCCL(ncclSend(d_src, bytes, ncclChar, mb.rank, g->comm, mb.s->stream));
+    FSA_NCCL(ncclRecv(d_dst, bytes, ncclChar, mb.rank, g->comm, mb.s->stream));
+    FSA_NCCL(ncclGroupEnd());
+    FSA_HIP(hipStreamSynchronize(mb.s->stream));
+    return FSA_OK;
+}
+
+int fsa_slab_group_destroy(fsa_slab_group *hg) {
+    Group *g = reinterpret_cast<Group *>(hg);
+    if (!g) return FSA_OK;
+    for (Member &mb : g->m) free_member(mb);
+    if (g->comm) (void)ncclCommDestroy(g->comm);
+    delete g;
+    return FSA_OK;
+}
+
+}  // extern "C"

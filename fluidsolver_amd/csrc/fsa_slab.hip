@@ -66,6 +66,8 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
     __shared__ int base[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = blockIdx.x * (kBlock * kPackItems);
+    n = live_count(P, n);
+    if (first >= n) return;
     Vec4<T> p[kPackItems];
     unsigned flags[kPackItems];  // bit 0 keep, 1 left, 2 right
     int before[kPackItems][3];   // flagged lanes below this one in its wave
@@ -276,6 +278,101 @@ __global__ __launch_bounds__(kBlock) void slab_init_keys_kernel(int n, const int
     if (i < n) key[i] = (long long)(unsigned)uniqueId[i];
 }
 
+// ---- exchange without host round trips (slab groups, fsa_group.hip) --------------------------------------------
+// (slabVars[]: fsa_solver.h)
+
+// After slab_pack_kernel: the counts leave the atomic counters (which go back to zero for the next pack), the
+// particle count becomes what stayed, each send buffer gets its count into its header slot, and a copy goes to
+// `mirror` (pinned host memory) for the host to read some steps later.  Counts beyond what the buffers take are
+// cut and flagged in slabVars[kVarError]: bit 0 capacity, 1 / 2 send buffer left / right.
+__global__ void slab_after_pack_kernel(int *__restrict__ counters, int *__restrict__ vars, int capKeep, int sizeLeft,
+                                       int sizeRight, long long *__restrict__ hdrLeft,
+                                       long long *__restrict__ hdrRight, int *__restrict__ mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int kept = counters[0], l = counters[1], r = counters[2], err = 0;
+    if (kept > capKeep) { kept = capKeep; err |= 1; }
+    if (l > sizeLeft) { l = sizeLeft; err |= 2; }
+    if (r > sizeRight) { r = sizeRight; err |= 4; }
+    vars[kVarN] = kept;
+    vars[kVarKept] = kept;
+    vars[kVarOutLeft] = l;
+    vars[kVarOutRight] = r;
+    vars[kVarLost] += counters[3];
+    vars[kVarError] |= err;
+    if (hdrLeft) hdrLeft[0] = l;
+    if (hdrRight) hdrRight[0] = r;
+    if (mirror) {
+        mirror[0] = l;
+        mirror[1] = r;
+        mirror[2] = kept;
+        mirror[3] = vars[kVarError];
+    }
+    counters[0] = counters[1] = counters[2] = counters[3] = 0;
+}
+
+// The counts of the two receive buffers as the unpack uses them (cut to what the message and the capacity take).
+__device__ __forceinline__ void incoming_counts(const long long *hdrLeft, const long long *hdrRight, int boundLeft,
+                                                int boundRight, int at, int capacity, int &cl, int &cr, int &err) {
+    err = 0;
+    long long l = hdrLeft ? hdrLeft[0] : 0, r = hdrRight ? hdrRight[0] : 0;
+    if (l < 0 || l > boundLeft) { l = l < 0 ? 0 : boundLeft; err |= 8; }
+    if (r < 0 || r > boundRight) { r = r < 0 ? 0 : boundRight; err |= 16; }
+    const long long room = (long long)capacity - at;
+    if (l + r > room) {
+        err |= 1;
+        if (l > room) l = room;
+        r = room - l;
+    }
+    cl = (int)l;
+    cr = (int)r;
+}
+
+// Appends the records of both receive buffers (left neighbour's first) behind the particles that stayed.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void slab_unpack_dev_kernel(const char *__restrict__ recvLeft,
+                                                                 const char *__restrict__ recvRight, int boundLeft,
+                                                                 int boundRight, const int *__restrict__ vars,
+                                                                 int capacity, Vec4<T> *__restrict__ posType,
+                                                                 Vec4<T> *__restrict__ velMass,
+                                                                 T *__restrict__ restDensity,
+                                                                 int *__restrict__ uniqueId,
+                                                                 long long *__restrict__ key) {
+    const int at = vars[kVarN];
+    int cl, cr, err;
+    incoming_counts((const long long *)recvLeft, (const long long *)recvRight, boundLeft, boundRight, at, capacity, cl,
+                    cr, err);
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= cl + cr) return;
+    const SlabRecord<T> *src = k < cl ? (const SlabRecord<T> *)(recvLeft + sizeof(SlabRecord<T>)) + k
+                                      : (const SlabRecord<T> *)(recvRight + sizeof(SlabRecord<T>)) + (k - cl);
+    const SlabRecord<T> r = *src;
+    posType[at + k] = r.posType;
+    velMass[at + k] = r.velMass;
+    restDensity[at + k] = r.restDensity;
+    uniqueId[at + k] = r.uniqueId;
+    key[at + k] = r.orderKey;
+}
+
+__global__ void slab_after_unpack_kernel(const char *__restrict__ recvLeft, const char *__restrict__ recvRight,
+                                         int boundLeft, int boundRight, int *__restrict__ vars, int capacity,
+                                         int *__restrict__ mirror) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int at = vars[kVarN];
+    int cl, cr, err;
+    incoming_counts((const long long *)recvLeft, (const long long *)recvRight, boundLeft, boundRight, at, capacity, cl,
+                    cr, err);
+    vars[kVarN] = at + cl + cr;
+    vars[kVarInLeft] = cl;
+    vars[kVarInRight] = cr;
+    vars[kVarError] |= err;
+    if (mirror) {
+        mirror[4] = cl;
+        mirror[5] = cr;
+        mirror[6] = at + cl + cr;
+        mirror[7] = vars[kVarError];
+    }
+}
+
 static inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 int launch_slab_init_keys(Solver *s) {
@@ -314,7 +411,7 @@ template <typename T>
 static int pack_t(Solver *s, const DevParams<T> &P, const SlabRanges &R, void *sendLeft, int capLeft, void *sendRight,
                   int capRight) {
     const int in = s->cur, out = 1 - s->cur;
-    hipLaunchKernelGGL(slab_pack_kernel<T>, dim3((s->n + kBlock * kPackItems - 1) / (kBlock * kPackItems)), dim3(kBlock), 0, s->stream, P, s->n,
+    hipLaunchKernelGGL(slab_pack_kernel<T>, dim3((s->grid_n() + kBlock * kPackItems - 1) / (kBlock * kPackItems)), dim3(kBlock), 0, s->stream, P, s->grid_n(),
                        s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (const Vec4<T> *)s->b.posType[in],
                        (const Vec4<T> *)s->b.velMass[in], (const T *)s->b.restDensity[in], s->b.uniqueId[in],
                        s->b.orderKey[in], (Vec4<T> *)s->b.posType[out], (Vec4<T> *)s->b.velMass[out],
@@ -376,6 +473,46 @@ int launch_slab_unpack(Solver *s, const void *recs, int count) {
                            s->n, (const SlabRecord<double> *)recs, (double4 *)s->b.posType[c],
                            (double4 *)s->b.velMass[c], (double *)s->b.restDensity[c], s->b.uniqueId[c],
                            s->b.orderKey[c]);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// Pack for a group step: no counts come back to the host.  sendLeft / sendRight are whole send buffers (header slot
+// first); sizeLeft / sizeRight the records this step's messages take.
+int launch_slab_pack_dev(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
+                         void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror) {
+    const int rb = slab_record_bytes(s);
+    ScopedTimer t(s, "slab_pack");
+    SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1]};
+    char *l = (char *)sendLeft, *r = (char *)sendRight;
+    int rc = s->precision == FSA_PRECISION_F32
+                 ? pack_t<float>(s, s->pf, R, l ? l + rb : nullptr, l ? sizeLeft : 0, r ? r + rb : nullptr, r ? sizeRight : 0)
+                 : pack_t<double>(s, s->pd, R, l ? l + rb : nullptr, l ? sizeLeft : 0, r ? r + rb : nullptr, r ? sizeRight : 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(slab_after_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->b.slabCounters, s->b.slabVars,
+                       s->capacity, l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_slab_unpack_dev(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
+                           int *mirror) {
+    ScopedTimer t(s, "slab_unpack");
+    const int c = s->cur, bound = (recvLeft ? boundLeft : 0) + (recvRight ? boundRight : 0);
+    if (bound > 0) {
+        if (s->precision == FSA_PRECISION_F32)
+            hipLaunchKernelGGL(slab_unpack_dev_kernel<float>, dim3(blocks_for(bound)), dim3(kBlock), 0, s->stream,
+                               (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
+                               s->capacity, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
+                               (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c]);
+        else
+            hipLaunchKernelGGL(slab_unpack_dev_kernel<double>, dim3(blocks_for(bound)), dim3(kBlock), 0, s->stream,
+                               (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
+                               s->capacity, (double4 *)s->b.posType[c], (double4 *)s->b.velMass[c],
+                               (double *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c]);
+    }
+    hipLaunchKernelGGL(slab_after_unpack_kernel, dim3(1), dim3(64), 0, s->stream, (const char *)recvLeft,
+                       (const char *)recvRight, boundLeft, boundRight, s->b.slabVars, s->capacity, mirror);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

@@ -75,6 +75,7 @@ struct Buffers {
     // z-slab runs only: order key of every particle (two copies like the hot set), pack counters
     long long *orderKey[2] = {nullptr, nullptr};
     int *slabCounters = nullptr;
+    int *slabVars = nullptr;     // particle count and exchange counts of a slab group step (fsa_slab.hip)
 };
 
 struct TimedLaunch {
@@ -99,6 +100,7 @@ struct Solver {
     bool hash_valid = false;    // hash/slot/cellCount describe the current arrays
     bool hash_ahead = false;    // the same, computed by the last step's integration pass (fsa_step); not what
                                 // the reference's particleHash holds after Advect, so read-back ignores it
+    bool count_stale = false;   // group steps have run since `n` was last read from the device (pf.count set)
     bool counts_clean = true;   // cellCount[] is all zero (as allocated; the fused scan leaves it so)
     bool perm_valid = false;    // sortedIndex/sortedHash/cellStart computed from hash
     bool sorted_valid = false;  // current arrays are in sorted order and cellStart matches them
@@ -133,6 +135,9 @@ struct Solver {
 
     size_t real_size() const { return precision == FSA_PRECISION_F64 ? sizeof(double) : sizeof(float); }
 };
+
+// slabVars[] of a z-slab solver in a group (device memory): the particle count and the counts of the last exchange
+enum { kVarN = 0, kVarKept, kVarOutLeft, kVarOutRight, kVarLost, kVarError, kVarInLeft, kVarInRight, kVarCount };
 
 // Sets the calling thread's error message and returns `code`.
 int fail(int code, const char *fmt, ...);
@@ -202,6 +207,10 @@ int launch_slab_keys(Solver *s);
 int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
                      void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
 int launch_slab_unpack(Solver *s, const void *recs, int count);
+int launch_slab_pack_dev(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
+                         void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror);
+int launch_slab_unpack_dev(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
+                           int *mirror);
 int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *count);
 int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
 int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);

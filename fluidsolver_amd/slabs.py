@@ -309,7 +309,8 @@ class SlabSolver:
     """One rank's share of a scene.  `backend_factory(params_dict, held, capacity)` builds the local
     solver (HipSlabBackend on a GPU); `transport` moves records between ranks."""
 
-    def __init__(self, scene, rank, world, transport, backend_factory, halo=HALO, slack=1.5, cuts=None):
+    def __init__(self, scene, rank, world, transport, backend_factory, halo=HALO, slack=1.5, cuts=None,
+                 exchange_buffers=True):
         P = scene["params"]
         self.rank, self.world, self.transport = rank, world, transport
         pos = np.asarray(scene["pos"], dtype=np.float32)
@@ -347,7 +348,8 @@ class SlabSolver:
         self.backend.set_scene_has_rigid(self.has_rigid)
         self.backend.set_owned(own)
         self.peers = [p for p in (rank - 1, rank + 1) if 0 <= p < world]
-        self._make_exchange_buffers()
+        if exchange_buffers:  # not when a native slab group (capi.SlabGroup) moves the records
+            self._make_exchange_buffers()
         self.lost = 0
         self.sent_records = 0
         self.recuts = 0

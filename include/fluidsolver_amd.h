@@ -378,6 +378,53 @@ int fsa_slab_set_owned(fsa_solver *s, const int own[2]);
 int fsa_slab_export_owned(fsa_solver *s, const int own[2], void *d_records, int cap, int *count);
 /* Appends `count` records from device memory (written by a neighbour's fsa_slab_pack). */
 int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
+
+/* ---- z-slab groups: the whole slab step, exchange included, without a host round trip ------------------
+ *
+ * Replaces the step loop of main.cpp:11-19 -> MultiphaseSPHSolver::Step (solver/MultiphaseSPHSolver.cpp:199-217)
+ * for a scene cut into z-slabs.  A group drives, per step and per slab: fsa_slab_pack's classification ->
+ * transport -> append -> hash, sort, density, force, integration, all queued on the solvers' streams.  The
+ * particle counts stay in device memory (they change with every exchange): fsa_slab_group_step returns
+ * without waiting, and any other entry point called on a member solver first waits for the queued steps.
+ * Members must be fp32 slab solvers on kernel variant 3 whose scene has no TYPE_RIGID particles; each must hold
+ * exactly the layers [cuts[r] - halo, cuts[r+1] + halo) (clipped to the grid) of its rank r.
+ *
+ *   local : all `world` slabs belong to solvers of THIS process, on one GPU or on several (one host program
+ *           driving a node, as the reference's main.cpp drives one GPU); records move by device-to-device copies.
+ *   rccl  : this process holds the slab of `rank`; its z-neighbours are other processes of the same
+ *           communicator.  Records move by ncclSend / ncclRecv (RCCL; xGMI inside a node), both neighbours in
+ *           one group call per step.  `id` comes from fsa_slab_group_unique_id on one rank and reaches the
+ *           others by whatever the host program uses (torch.distributed, MPI, a file).
+ *
+ * Messages are sized from the counts of three steps earlier plus head room (record_cap = the most records one
+ * message may ever carry).  If a count outgrows its message or a solver's capacity, the excess is dropped,
+ * flagged on the device, and fsa_slab_group_sync (or the next entry point used on the solver) returns
+ * FSA_ERR_CAPACITY: the state is then invalid.
+ */
+typedef struct fsa_slab_group fsa_slab_group;
+#define FSA_SLAB_GROUP_ID_BYTES 128
+typedef struct fsa_slab_group_stats {
+    long long steps;         /* steps queued since the group was made */
+    long long particles;     /* held by this process's members now (halo copies included) */
+    long long max_particles; /* the largest member */
+    long long lost;          /* particles that left every range they could go to (no neighbour holds their layer) */
+    long long records_sent;  /* by this process's members, up to three steps ago */
+    int error_bits;          /* 0, or what overflowed: 1 capacity, 2/4 message out left/right, 8/16 in left/right */
+} fsa_slab_group_stats;
+int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts /* world + 1 */, int halo,
+                                int record_cap, fsa_slab_group **out);
+int fsa_slab_group_unique_id(char id[FSA_SLAB_GROUP_ID_BYTES]);
+int fsa_slab_group_create_rccl(fsa_solver *solver, int rank, int world, const char id[FSA_SLAB_GROUP_ID_BYTES],
+                               const int *cuts /* world + 1 */, int halo, int record_cap, fsa_slab_group **out);
+/* Queues nsteps steps; returns without waiting for them. */
+int fsa_slab_group_step(fsa_slab_group *g, int nsteps);
+/* Waits for everything queued, brings the member solvers' host-side counts up to date, fills *st (may be NULL). */
+int fsa_slab_group_sync(fsa_slab_group *g, fsa_slab_group_stats *st);
+/* Self test of the RCCL transport: sends `bytes` from d_src to this very rank's d_dst through the group's
+ * communicator on the member's stream, and waits. */
+int fsa_slab_group_rccl_loopback(fsa_slab_group *g, const void *d_src, void *d_dst, size_t bytes);
+/* Waits, hands the counts back to the solvers (which live on), frees the group's buffers. */
+int fsa_slab_group_destroy(fsa_slab_group *g);
 /* Overrides the scan of `type` that fsa_upload does: whether a TYPE_RIGID particle can ever be held by
  * this solver (in a slab run one may arrive from a neighbour later). */
 int fsa_set_scene_has_rigid(fsa_solver *s, int has_rigid);

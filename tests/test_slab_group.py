@@ -1,0 +1,117 @@
+"""Native slab groups (fsa_slab_group_*): the slab step with the exchange inside the library and no host round
+trip per step.  All slabs in one process on the one GPU of the test box (the `local` transport, one stream per
+solver), against the plain single-solver run, bit for bit; the RCCL transport with the one rank a single GPU
+allows, plus its loop-back self test."""
+import numpy as np
+import pytest
+
+from fluidsolver_amd import capi, slabs
+from test_slabs_cpu import assert_same_bits, merged
+from test_slabs_gpu import plain_gpu_run
+from slab_worker import SCENES
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 25
+
+
+def make_ranks(sc, world, cuts=None):
+    return [slabs.SlabSolver(sc, r, world, None, lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, 3),
+                             cuts=cuts, exchange_buffers=False) for r in range(world)]
+
+
+@pytest.mark.parametrize("scene", ["dam", "ddam"])
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_local_group_equals_plain_solver(scene, world):
+    sc = SCENES[scene]()
+    ref = plain_gpu_run(sc, STEPS, 3)
+    ranks = make_ranks(sc, world)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    g.step(7)
+    g.step(STEPS - 7)  # no sync in between: the second call queues behind the first
+    st = g.sync()
+    assert st.steps == STEPS and st.lost == 0 and st.error_bits == 0
+    if world > 1:
+        assert st.records_sent > 0
+    parts = [ss.owned() for ss in ranks]
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, ref)
+    assert st.particles == sum(ss.backend.n for ss in ranks)
+    g.close()
+    # the solvers live on with a host-side count
+    n0 = ranks[0].backend.n
+    ranks[0].backend.solver.sort_particles()
+    assert ranks[0].backend.n == n0
+    for ss in ranks:
+        ss.close()
+
+
+def test_local_group_lopsided_cuts_and_stepwise_sync():
+    """three slabs with very uneven cuts, synchronising (and reading buffers) every few steps"""
+    sc = SCENES["dam"]()
+    gz = slabs.derive_grid(sc["params"])["gridres"][2]
+    ranks = make_ranks(sc, 3, cuts=[0, 3, 6, gz])
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], [0, 3, 6, gz], slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    done = 0
+    for k in (1, 2, 5, 9, 8):
+        g.step(k)
+        done += k
+        _ = ranks[1].backend.get("pos")  # any entry point on a member waits for the queued steps
+    assert done == STEPS
+    st = g.sync()
+    assert st.lost == 0
+    uid, got = merged([ss.owned() for ss in ranks])
+    assert_same_bits(uid, got, plain_gpu_run(sc, STEPS, 3))
+    g.close()
+    for ss in ranks:
+        ss.close()
+
+
+def test_group_reports_an_outgrown_message():
+    sc = SCENES["dam"]()
+    ranks = make_ranks(sc, 2)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO, 16)
+    g.step(2)
+    with pytest.raises(capi.FsaError, match="outgrew"):
+        g.sync()
+    g.close()
+    for ss in ranks:
+        ss.close()
+
+
+def test_group_refuses_unfit_solvers():
+    sc = SCENES["dam"]()
+    ranks = make_ranks(sc, 2)
+    ranks[0].backend.solver.set_variant(2)
+    with pytest.raises(capi.FsaError, match="variant 3"):
+        capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO, 1000)
+    ranks[0].backend.solver.set_variant(3)
+    with pytest.raises(capi.FsaError, match="holds layers"):
+        capi.SlabGroup.local([ss.backend.solver for ss in ranks], [0, 4, ranks[0].layout.cuts[-1]], slabs.HALO, 1000)
+    for ss in ranks:
+        ss.close()
+
+
+def test_rccl_group_single_rank_and_loopback():
+    """the RCCL transport as far as one GPU goes: communicator of one rank, the group step on it (no neighbours, so
+    nothing travels), and a send to itself through the communicator on the solver's stream"""
+    import torch
+    sc = SCENES["dam"]()
+    ref = plain_gpu_run(sc, STEPS, 3)
+    ranks = make_ranks(sc, 1)
+    ss = ranks[0]
+    g = capi.SlabGroup.rccl(ss.backend.solver, 0, 1, capi.SlabGroup.unique_id(), ss.layout.cuts, slabs.HALO, 4096)
+    g.step(STEPS)
+    st = g.sync()
+    assert st.lost == 0 and st.error_bits == 0
+    uid, got = merged([ss.owned()])
+    assert_same_bits(uid, got, ref)
+    src = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    g.rccl_loopback(src.data_ptr(), dst.data_ptr(), src.numel() * 4)
+    assert torch.equal(src, dst)
+    g.close()
+    ss.close()
