@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--jitter", type=float, default=float(os.environ.get("FSA_BENCH_JITTER", 0.0)),
                     help="uniform position noise in units of the particle spacing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--recut-every", type=int, default=int(os.environ.get("FSA_BENCH_RECUT_EVERY", 0)),
+                    help="slab runs: re-balance the z-cuts every k steps (scenes whose mass moves along z)")
     ap.add_argument("--variant", type=int, default=None)
     return ap.parse_args()
 
@@ -228,8 +230,10 @@ def main():
                    "particles_total": res["n"], "particles_counted": res["n_fluid"], "grid": res["gridres"],
                    "spinup_steps": args.spinup, "parallelism": f"z-slabs x{args.gpus}" if args.gpus > 1 else "1 GPU",
                    "out_of_grid_particles": res["n_undef"],
-                   **{k: res[k] for k in ("comm_backend", "slab_cuts", "halo_layers", "max_local_particles",
-                                          "lost_particles", "records_sent_per_step") if k in res}},
+                   **{k: res[k] for k in ("comm_backend", "slab_step", "slab_cuts", "halo_layers",
+                                          "max_local_particles", "mean_local_particles", "lost_particles",
+                                          "records_sent_per_step", "exchange_ms_per_step_max",
+                                          "host_syncs_in_timed_steps", "recuts", "recut_every") if k in res}},
         "roofline": roof, "roofline_all": {"unit": "GB/s", "peak": HBM_PEAK_GBS, "kernels": roof_all},
         "kernels": kernels,
     }

@@ -185,6 +185,9 @@ def load() -> C.CDLL:
         f = getattr(lib, name)
         f.restype = C.c_int
         f.argtypes = args
+    for name in ("fsa_debug_host_waits", "fsa_debug_event_waits"):  # not in the public header
+        getattr(lib, name).restype = C.c_longlong
+        getattr(lib, name).argtypes = []
     _lib = lib
     return lib
 

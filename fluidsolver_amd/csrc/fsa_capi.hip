@@ -5,12 +5,31 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <new>
 
 #include "fsa_solver.h"
 #include "fsa_tile.h"
 
 namespace fsa {
+
+static std::atomic<long long> g_host_waits{0};
+hipError_t counted_stream_sync(hipStream_t st) {
+    g_host_waits++;
+    return hipStreamSynchronize(st);
+}
+hipError_t counted_device_sync() {
+    g_host_waits++;
+    return hipDeviceSynchronize();
+}
+// An event of some steps ago (slab groups): waiting for it only keeps the host from running further ahead of the
+// device, which still has the steps in between queued; counted apart.
+static std::atomic<long long> g_event_waits{0};
+hipError_t counted_event_sync(hipEvent_t ev) {
+    if (hipEventQuery(ev) == hipSuccess) return hipSuccess;
+    g_event_waits++;
+    return hipEventSynchronize(ev);
+}
 
 static thread_local char g_err[512] = "";
 
@@ -178,7 +197,7 @@ using namespace fsa;
 // waits for the queued steps first.
 static int refresh_count(Solver *s) {
     if (!s->count_stale) return FSA_OK;
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     int vars[kVarCount];
     FSA_HIP(hipMemcpy(vars, s->b.slabVars, sizeof(vars), hipMemcpyDeviceToHost));
     s->n = vars[kVarN];
@@ -350,7 +369,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     s->pf.rows = s->b.blockRows;
     s->pf.big = s->b.bigBlocks;
     // the zero fills above ran on the NULL stream, which the solver's non-blocking stream does not wait for
-    if (hipDeviceSynchronize() != hipSuccess) {
+    if (counted_device_sync() != hipSuccess) {
         free_all(s);
         delete s;
         return fail(FSA_ERR_HIP, "hipDeviceSynchronize failed after the allocations");
@@ -363,7 +382,7 @@ int fsa_destroy(fsa_solver *hs) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     if (!s) return FSA_OK;
     (void)hipSetDevice(s->device);
-    (void)hipStreamSynchronize(s->stream);
+    (void)counted_stream_sync(s->stream);
     free_all(s);
     delete s;
     return FSA_OK;
@@ -393,7 +412,7 @@ int fsa_copy_param_to_device(fsa_solver *hs, const fsa_params *p) {
 int fsa_set_stream(fsa_solver *hs, void *hip_stream) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
     return FSA_OK;
 }
@@ -401,7 +420,7 @@ int fsa_set_stream(fsa_solver *hs, void *hip_stream) {
 int fsa_synchronize(fsa_solver *hs) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     return FSA_OK;
 }
 
@@ -424,7 +443,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
             seen[u] = 1;
         }
     }
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     s->has_rigid = false;
     for (size_t i = 0; i < N; i++)
         if (type[i] == FSA_TYPE_RIGID) s->has_rigid = true;
@@ -484,7 +503,7 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     FSA_HIP(hipMemsetAsync(s->b.v_star, 0, N * 3 * R, s->stream));
     FSA_HIP(hipMemsetAsync(s->b.density, 0, N * R, s->stream));
     FSA_HIP(hipMemsetAsync(s->b.pressure, 0, N * R, s->stream));
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     return FSA_OK;
 }
 
@@ -502,7 +521,7 @@ int fsa_num_undef(fsa_solver *hs, int *n) {
     if (!n) return fail(FSA_ERR_INVALID, "n is NULL");
     if (!s->count_valid) return fail(FSA_ERR_INVALID, "no sort has run since the last upload");
     int in_grid = 0;
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     FSA_HIP(hipMemcpy(&in_grid, s->b.cellStart + s->num_cells, sizeof(int), hipMemcpyDeviceToHost));
     *n = s->n - in_grid;
     return FSA_OK;
@@ -643,7 +662,7 @@ int fsa_readback_pos_color(fsa_solver *hs, void *pos3, void *color4, int *n) {
         Staging st;
         TRY(st.alloc(N * 3 * R));
         TRY(launch_unpack_vec3(s, s->b.posType[s->cur], st.d, s->n));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         FSA_HIP(hipMemcpy(pos3, st.d, N * 3 * R, hipMemcpyDeviceToHost));
     }
     if (color4 && s->slab) return fail(FSA_ERR_INVALID, "a slab solver does not store color");
@@ -651,14 +670,14 @@ int fsa_readback_pos_color(fsa_solver *hs, void *pos3, void *color4, int *n) {
         Staging st;
         TRY(st.alloc(N * 4 * R));
         TRY(launch_gather_by_uid(s, s->b.color, st.d, s->n, (int)(4 * R / 4)));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         FSA_HIP(hipMemcpy(color4, st.d, N * 4 * R, hipMemcpyDeviceToHost));
     }
     return FSA_OK;
 }
 
 static int copy_out(Solver *s, const void *dsrc, void *dst, size_t bytes) {
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     if (bytes) FSA_HIP(hipMemcpy(dst, dsrc, bytes, hipMemcpyDeviceToHost));
     return FSA_OK;
 }
@@ -706,7 +725,7 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
             return fail(FSA_ERR_INVALID, "neighbourCount needs a sorted fp32 state with lists enabled");
         TRY(ensure_lists(s));
         std::vector<unsigned short> h(N);
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         if (N) FSA_HIP(hipMemcpy(h.data(), s->b.nbCount, N * sizeof(unsigned short), hipMemcpyDeviceToHost));
         int *out = (int *)dst;
         for (size_t i = 0; i < N; i++) out[i] = h[i] == 0xffff ? -1 : (int)h[i];
@@ -716,7 +735,7 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
         TRY(want(N * sizeof(int)));
         if (!s->hits_valid) return fail(FSA_ERR_INVALID, "hitCount needs the record of a variant-3 density or force pass");
         std::vector<unsigned char> h(N);
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         if (N) FSA_HIP(hipMemcpy(h.data(), s->b.hitCount, N, hipMemcpyDeviceToHost));
         int *out = (int *)dst;
         for (size_t i = 0; i < N; i++) out[i] = h[i] == 255 ? -1 : (int)h[i];
@@ -800,7 +819,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
         return FSA_OK;
     };
     const int c = s->cur;
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     s->pd_valid = false;  // density, pressure, mass or viscosity may change under it
     s->lists_valid = false;
     s->hits_valid = false;
@@ -830,7 +849,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
         TRY(st.alloc(bytes));
         if (bytes) FSA_HIP(hipMemcpy(st.d, src, bytes, hipMemcpyHostToDevice));
         TRY(launch_set_xyz(s, k == "pos" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         if (k == "pos") invalidate_order(s);
         return FSA_OK;
     }
@@ -845,7 +864,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
                 if (((const int *)src)[i] == FSA_TYPE_RIGID) s->has_rigid = true;
         }
         TRY(launch_set_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         return FSA_OK;
     }
     return fail(FSA_ERR_UNKNOWN_NAME, "buffer '%s' cannot be set", name);
@@ -862,7 +881,7 @@ int fsa_timing_enable(fsa_solver *hs, int on) {
 int fsa_timing_reset(fsa_solver *hs) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     for (auto &t : s->launches) {
         s->event_pool.push_back(t.start);
         s->event_pool.push_back(t.stop);
@@ -875,7 +894,7 @@ int fsa_timing_read(fsa_solver *hs, fsa_kernel_time *out, int cap, int *count) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
     if (!count || (cap > 0 && !out)) return fail(FSA_ERR_INVALID, "NULL argument");
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     const int K = (int)s->kernel_names.size();
     std::vector<double> ms(K, 0.0);
     std::vector<int> cnt(K, 0);
@@ -1016,7 +1035,7 @@ int fsa_set_volume_fractions(fsa_solver *hs, int typenum, const double *dens_arr
     if (s->slab) return fail(FSA_ERR_INVALID, "fsa_set_volume_fractions is not available in a slab solver");
     if (typenum < 1 || typenum > 10) return fail(FSA_ERR_INVALID, "typenum %d outside 1..10", typenum);
     if (!dens_arr || (s->n > 0 && !vfrac)) return fail(FSA_ERR_INVALID, "NULL argument");
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     const size_t N = (size_t)s->n, R = s->real_size(), K = (size_t)typenum;
     if (typenum != s->typenum) {  // the one allocation after fsa_create, sized for the solver's capacity
         if (s->b.vFrac) (void)hipFree(s->b.vFrac);
@@ -1190,6 +1209,11 @@ int fsa_set_scene_has_rigid(fsa_solver *hs, int has_rigid) {
     s->has_rigid = has_rigid != 0;
     return FSA_OK;
 }
+
+// Not part of the public header: how often the library has made the host wait for the device so far.
+long long fsa_debug_host_waits(void) { return g_host_waits.load(); }
+// ... and how often it has waited for an event recorded some steps earlier (the device was not idle meanwhile)
+long long fsa_debug_event_waits(void) { return g_event_waits.load(); }
 
 // Not part of the public header: kernel-ablation timing used by tools/ablate.py.
 int fsa_debug_time_pass(fsa_solver *hs, int which, int ablate, int reps) {

@@ -481,13 +481,13 @@ int launch_max_error(Solver *s, double start, double *out) {
         float v = 0.f;
         FSA_HIP(hipMemcpyAsync(&v, (const float *)s->b.reduce_tmp + kReduceBlocks, sizeof(v), hipMemcpyDeviceToHost,
                                s->stream));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         *out = v;
     } else {
         double v = 0.0;
         FSA_HIP(hipMemcpyAsync(&v, (const double *)s->b.reduce_tmp + kReduceBlocks, sizeof(v), hipMemcpyDeviceToHost,
                                s->stream));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         *out = v;
     }
     return FSA_OK;

@@ -832,7 +832,7 @@ static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, 
             GRID_LAUNCH(cg_direction_kernel<T>, nb, G, g->cg, round, (const T *)g->r, (T *)g->q);
         }
         FSA_HIP(hipMemcpyAsync(&st, g->cg, sizeof(st), hipMemcpyDeviceToHost, g->stream));
-        FSA_HIP(hipStreamSynchronize(g->stream));
+        FSA_HIP(counted_stream_sync(g->stream));
         if (st.finished || st.pending) break;
     }
     if (st.finished == 2)
@@ -935,7 +935,7 @@ int fsa_grid_destroy(fsa_grid *hg) {
     GridSolver *g = reinterpret_cast<GridSolver *>(hg);
     if (!g) return FSA_OK;
     (void)hipSetDevice(g->device);
-    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->stream) (void)counted_stream_sync(g->stream);
     grid_free(g);
     delete g;
     return FSA_OK;
@@ -958,7 +958,7 @@ int fsa_grid_sizes(fsa_grid *hg, int sizes[4], double xmin[3]) {
 int fsa_grid_synchronize(fsa_grid *hg) {
     GridSolver *g = reinterpret_cast<GridSolver *>(hg);
     GNEED(g);
-    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(counted_stream_sync(g->stream));
     return FSA_OK;
 }
 
@@ -971,7 +971,7 @@ int fsa_grid_get_field(fsa_grid *hg, const char *name, void *dst, size_t bytes) 
     if (!p) return fail(FSA_ERR_UNKNOWN_NAME, "unknown grid field '%s'", name);
     if (bytes != count * g->real_size())
         return fail(FSA_ERR_INVALID, "field '%s' is %zu bytes, caller passed %zu", name, count * g->real_size(), bytes);
-    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(counted_stream_sync(g->stream));
     FSA_HIP(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
     return FSA_OK;
 }
@@ -985,7 +985,7 @@ int fsa_grid_set_field(fsa_grid *hg, const char *name, const void *src, size_t b
     if (!p) return fail(FSA_ERR_UNKNOWN_NAME, "unknown grid field '%s'", name);
     if (bytes != count * g->real_size())
         return fail(FSA_ERR_INVALID, "field '%s' is %zu bytes, caller passed %zu", name, count * g->real_size(), bytes);
-    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(counted_stream_sync(g->stream));
     FSA_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     return FSA_OK;
 }
@@ -994,7 +994,7 @@ int fsa_grid_set_particles(fsa_grid *hg, int n, const void *pos3) {
     GridSolver *g = reinterpret_cast<GridSolver *>(hg);
     GNEED(g);
     if (n < 0 || (n > 0 && !pos3)) return fail(FSA_ERR_INVALID, "bad particle array");
-    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(counted_stream_sync(g->stream));
     const size_t R = g->real_size();
     if (n > g->particle_cap) {
         if (g->ppos) (void)hipFree(g->ppos);
@@ -1023,7 +1023,7 @@ int fsa_grid_get_particles(fsa_grid *hg, void *pos3, void *color4, int *n) {
     GridSolver *g = reinterpret_cast<GridSolver *>(hg);
     GNEED(g);
     if (n) *n = g->n_particles;
-    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(counted_stream_sync(g->stream));
     const size_t R = g->real_size(), N = (size_t)g->n_particles;
     if (N == 0) return FSA_OK;
     if (pos3) FSA_HIP(hipMemcpy(pos3, g->ppos, N * 3 * R, hipMemcpyDeviceToHost));
@@ -1062,7 +1062,7 @@ int fsa_grid_div_velocity(fsa_grid *hg, double *div_u_sum) {
     GTRY(grid_div(g, false));
     if (div_u_sum) {
         FSA_HIP(hipMemcpyAsync(div_u_sum, g->divsum, sizeof(double), hipMemcpyDeviceToHost, g->stream));
-        FSA_HIP(hipStreamSynchronize(g->stream));
+        FSA_HIP(counted_stream_sync(g->stream));
     }
     return FSA_OK;
 }
@@ -1114,7 +1114,7 @@ int fsa_grid_dotproduct(fsa_grid *hg, const char *a_name, const char *b_name, do
     FSA_HIP(hipGetLastError());
     double s = 0.0;
     FSA_HIP(hipMemcpyAsync(&s, g->divsum, sizeof(double), hipMemcpyDeviceToHost, g->stream));
-    FSA_HIP(hipStreamSynchronize(g->stream));
+    FSA_HIP(counted_stream_sync(g->stream));
     *out = g->precision == FSA_PRECISION_F32 ? (double)(float)s : s;
     return FSA_OK;
 }

@@ -87,7 +87,7 @@ static void held_of(const Group &g, int r, int out[2]) {
 static void free_member(Member &mb) {
     if (mb.s) {
         (void)hipSetDevice(mb.s->device);
-        (void)hipStreamSynchronize(mb.s->stream);
+        (void)counted_stream_sync(mb.s->stream);
         // the solver goes back to a host-side count
         if (mb.s->pf.count) {
             int n = mb.s->n;
@@ -143,12 +143,12 @@ static int setup_member(Group &g, Member &mb, Solver *s, int rank) {
     FSA_HIP(hipHostMalloc((void **)&mb.mirror, sizeof(int) * kRing * kMirrorInts, hipHostMallocDefault));
     std::memset(mb.mirror, 0, sizeof(int) * kRing * kMirrorInts);
     // from here on the count lives on the device
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     int vars[16] = {0};
     vars[kVarN] = s->n;
     FSA_HIP(hipMemcpy(s->b.slabVars, vars, sizeof(vars), hipMemcpyHostToDevice));
     FSA_HIP(hipMemset(s->b.slabCounters, 0, 8 * sizeof(int)));
-    FSA_HIP(hipDeviceSynchronize());
+    FSA_HIP(counted_device_sync());
     s->pf.count = s->pd.count = s->b.slabVars + kVarN;
     s->pf.own_lo = s->pd.own_lo = mb.own[0];
     s->pf.own_hi = s->pd.own_hi = mb.own[1];
@@ -160,7 +160,7 @@ static int outgoing_sizes(Group &g, Member &mb) {
     for (int d = 0; d < 2; d++) mb.size_out[d] = g.record_cap;
     if (g.step >= kLag) {
         const int slot = (int)((g.step - kLag) % kRing);
-        FSA_HIP(hipEventSynchronize(mb.ev_pack[slot]));  // long done: no wait in steady state
+        FSA_HIP(counted_event_sync(mb.ev_pack[slot]));  // long done: no wait in steady state
         const int *mi = mb.mirror + slot * kMirrorInts;
         for (int d = 0; d < 2; d++) mb.size_out[d] = next_size(mi[d], g.record_cap);
         g.sent += (long long)mi[0] + mi[1];
@@ -173,7 +173,7 @@ static int incoming_sizes(Group &g, Member &mb, int size_in[2]) {
     size_in[0] = size_in[1] = g.record_cap;
     if (g.step >= kLag) {
         const int slot = (int)((g.step - kLag) % kRing);
-        FSA_HIP(hipEventSynchronize(mb.ev_unpack[slot]));
+        FSA_HIP(counted_event_sync(mb.ev_unpack[slot]));
         const int *mi = mb.mirror + slot * kMirrorInts;
         for (int d = 0; d < 2; d++) size_in[d] = next_size(mi[4 + d], g.record_cap);
     }
@@ -219,6 +219,7 @@ static int group_step(Group &g) {
         for (Member &mb : g.m) {
             Solver *s = mb.s;
             FSA_HIP(hipSetDevice(s->device));
+            ScopedTimer t(s, "exchange");
             for (int d = 0; d < 2; d++) {
                 if (!mb.send[d]) continue;
                 Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
@@ -238,6 +239,7 @@ static int group_step(Group &g) {
         Solver *s = mb.s;
         int rc = incoming_sizes(g, mb, size_in);
         if (rc) return rc;
+        ScopedTimer t(s, "exchange");
         FSA_NCCL(ncclGroupStart());
         for (int d = 0; d < 2; d++) {
             if (!mb.send[d]) continue;
@@ -371,7 +373,7 @@ int fsa_slab_group_sync(fsa_slab_group *hg, fsa_slab_group_stats *st) {
     for (Member &mb : g->m) {
         Solver *s = mb.s;
         FSA_HIP(hipSetDevice(s->device));
-        FSA_HIP(hipStreamSynchronize(s->stream));
+        FSA_HIP(counted_stream_sync(s->stream));
         int vars[8];
         FSA_HIP(hipMemcpy(vars, s->b.slabVars, sizeof(vars), hipMemcpyDeviceToHost));
         s->n = vars[kVarN];
@@ -405,7 +407,7 @@ int fsa_slab_group_rccl_loopback(fsa_slab_group *hg, const void *d_src, void *d_
     FSA_NCCL(ncclSend(d_src, bytes, ncclChar, mb.rank, g->comm, mb.s->stream));
     FSA_NCCL(ncclRecv(d_dst, bytes, ncclChar, mb.rank, g->comm, mb.s->stream));
     FSA_NCCL(ncclGroupEnd());
-    FSA_HIP(hipStreamSynchronize(mb.s->stream));
+    FSA_HIP(counted_stream_sync(mb.s->stream));
     return FSA_OK;
 }
 

@@ -824,7 +824,7 @@ int launch_mean_error(Solver *s, double *out) {
     double sum = 0.0;
     FSA_HIP(hipMemcpyAsync(&sum, (const double *)s->b.reduce_tmp + kSumBlocks, sizeof(sum), hipMemcpyDeviceToHost,
                            s->stream));
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     const double mean = sum / (double)n;
     *out = s->precision == FSA_PRECISION_F32 ? (double)(float)mean : mean;
     return FSA_OK;

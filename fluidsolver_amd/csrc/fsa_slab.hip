@@ -433,7 +433,7 @@ int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int l
         if (rc) return rc;
     }
     FSA_HIP(hipMemcpyAsync(counts, s->b.slabCounters, 4 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     return FSA_OK;
 }
 
@@ -456,7 +456,7 @@ int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *co
         FSA_HIP(hipGetLastError());
     }
     FSA_HIP(hipMemcpyAsync(count, s->b.slabCounters, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    FSA_HIP(hipStreamSynchronize(s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
     return FSA_OK;
 }
 

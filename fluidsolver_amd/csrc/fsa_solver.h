@@ -139,6 +139,12 @@ struct Solver {
 // slabVars[] of a z-slab solver in a group (device memory): the particle count and the counts of the last exchange
 enum { kVarN = 0, kVarKept, kVarOutLeft, kVarOutRight, kVarLost, kVarError, kVarInLeft, kVarInRight, kVarCount };
 
+// Every place where the library makes the host wait for the device goes through these, which count the waits
+// (fsa_debug_host_waits: tests assert that a slab group step makes none).
+hipError_t counted_stream_sync(hipStream_t st);
+hipError_t counted_device_sync();
+hipError_t counted_event_sync(hipEvent_t ev);  // counted apart, and only if the event had not completed yet
+
 // Sets the calling thread's error message and returns `code`.
 int fail(int code, const char *fmt, ...);
 // Argument check of a caller's parameter block, and its fp32 device form (fsa_capi.hip).

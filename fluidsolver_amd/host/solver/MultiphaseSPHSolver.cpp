@@ -296,6 +296,9 @@ void MultiphaseSPHSolver::Setup() {
     SetupSPH();
     // resume from a text checkpoint written by key 'b' (DumpSimulationDataText)
     if (const char *resume = std::getenv("FSA_RESUME")) LoadSimulationDataText(resume);
+    // several z-slabs under this one host program (slab_mode.cpp)
+    if (const char *slabs = std::getenv("FSA_SLABS"))
+        if (std::atoi(slabs) > 0 && numParticles > 0) EnterSlabMode(std::atoi(slabs));
 }
 
 // Text checkpoint of solver/MultiphaseSPHSolver.cpp:219-247: the single-phase line plus the volume fractions.

@@ -1,0 +1,207 @@
+// Several z-slabs driven by ONE host program (FSA_SLABS=N): the plugin surface of main.cpp stays as it is, the
+// SPH (WCSPH) step underneath runs as a slab group of the library (fsa_slab_group_create_local): N device solvers,
+// on one GPU or spread over FSA_SLAB_DEVICES GPUs, exchanging migrants and halo copies by device-to-device copies
+// with no host round trip per step.  Replaces the single `device` of SPHSolver::Step
+// (solver/sph_solver.cpp:129-142 under /root/reference/particle_solver) for scenes too large or too slow for one
+// GPU.  Results are those of the single-solver run, bit for bit.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+
+#include "sph_solver.h"
+
+namespace {
+
+constexpr int kHalo = 2;
+constexpr unsigned kUndef = 99999999u;
+
+// cell layer (z index) of a position with the arithmetic of calcGridPos / calcHashD
+// (solver/sph_kernel_impl.cuh:74-100): fp32 subtract, divide, floor; -1 outside the domain
+int cell_layer(const cfloat3 &p, const fsa_params &P) {
+    const float x[3] = {p.x, p.y, p.z};
+    int cell[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = (float)P.gridxmin[a], hi = (float)P.gridxmax[a];
+        if (!((double)x[a] < (double)hi - 1e-10 && (double)x[a] > (double)lo + 1e-10)) return -1;
+        cell[a] = (int)std::floor((x[a] - lo) / (float)P.dx);
+        if (cell[a] < 0 || cell[a] >= P.gridres[a]) return -1;
+    }
+    return cell[2];
+}
+
+// cut indices that balance the particle counts, every slab at least min_layers thick
+std::vector<int> balanced_cuts(const std::vector<long long> &hist, int nranks, int min_layers) {
+    const int gz = (int)hist.size();
+    std::vector<double> pre(gz + 1, 0.0);
+    for (int z = 0; z < gz; z++) pre[z + 1] = pre[z] + (double)hist[z];
+    std::vector<int> cuts{0};
+    for (int r = 1; r < nranks; r++) {
+        const double target = pre[gz] * r / nranks;
+        int c = (int)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin());
+        if (c > 0 && std::fabs(pre[c - 1] - target) <= std::fabs(pre[std::min(c, gz)] - target)) c--;
+        c = std::max(c, cuts.back() + min_layers);
+        c = std::min(c, gz - (nranks - r) * min_layers);
+        cuts.push_back(c);
+    }
+    cuts.push_back(gz);
+    return cuts;
+}
+
+}  // namespace
+
+void SPHSolver::LeaveSlabMode() {
+    if (slab_group) fsa_slab_group_destroy(slab_group);
+    slab_group = nullptr;
+    for (fsa_solver *s : slab_devices) fsa_destroy(s);
+    slab_devices.clear();
+}
+
+// Called at the end of the set-up, with the scene on `device` in its sorted order: that state is cut into
+// nslabs slabs and `device` is released.
+void SPHSolver::EnterSlabMode(int nslabs) {
+    if (run_mode != SPH) {
+        std::fprintf(stderr, "FSA_SLABS: only the SPH (WCSPH) step runs on several slabs\n");
+        std::exit(EXIT_FAILURE);
+    }
+    const int n = numParticles;
+    const int gz = hParam.gridres[2];
+    if (nslabs < 1 || gz < nslabs * (kHalo + 1)) {
+        std::fprintf(stderr, "FSA_SLABS=%d: %d cell layers cannot be cut into that many slabs of at least %d\n", nslabs, gz,
+                     kHalo + 1);
+        std::exit(EXIT_FAILURE);
+    }
+    // the state in device order; a particle's slab id is its place in that order, which makes the order keys of
+    // the slabs' first sort break ties exactly as the single solver's next sort would
+    vecf3 p((size_t)n), v((size_t)n);
+    vecf m((size_t)n), rd((size_t)n);
+    veci t((size_t)n);
+    slab_color.resize((size_t)n);
+    int got = 0;
+    check(fsa_readback_pos_color(device, p.data(), slab_color.data(), &got), "fsa_readback_pos_color");
+    check(fsa_get_buffer(device, "vel", v.data(), (size_t)n * sizeof(cfloat3)), "get vel");
+    check(fsa_get_buffer(device, "type", t.data(), (size_t)n * sizeof(int)), "get type");
+    check(fsa_get_buffer(device, "mass", m.data(), (size_t)n * sizeof(float)), "get mass");
+    check(fsa_get_buffer(device, "restDensity", rd.data(), (size_t)n * sizeof(float)), "get restDensity");
+    for (int i = 0; i < n; i++)
+        if (t[i] == TYPE_RIGID) {
+            std::fprintf(stderr, "FSA_SLABS: scenes with TYPE_RIGID particles run on one solver only\n");
+            std::exit(EXIT_FAILURE);
+        }
+    fsa_destroy(device);
+    device = nullptr;
+
+    veci layer((size_t)n);
+    std::vector<long long> hist((size_t)gz, 0);
+    long long outside = 0;
+    for (int i = 0; i < n; i++) {
+        layer[i] = cell_layer(p[i], hParam);
+        if (layer[i] >= 0) hist[layer[i]]++;
+        else outside++;
+    }
+    slab_cuts = nslabs > 1 ? balanced_cuts(hist, nslabs, kHalo + 1) : std::vector<int>{0, gz};
+    std::vector<long long> pre((size_t)gz + 1, 0);
+    for (int z = 0; z < gz; z++) pre[z + 1] = pre[z] + hist[z];
+    auto held = [&](int r, int out[2]) {
+        out[0] = std::max(slab_cuts[r] - kHalo, 0);
+        out[1] = std::min(slab_cuts[r + 1] + kHalo, gz);
+    };
+    long long most = 0, widest = 0;
+    for (int r = 0; r < nslabs; r++) {
+        int h[2];
+        held(r, h);
+        most = std::max(most, pre[h[1]] - pre[h[0]]);
+    }
+    for (int r = 1; r < nslabs; r++) {
+        const int c = slab_cuts[r];
+        widest = std::max(widest, pre[std::min(c + 2 * kHalo, gz)] - pre[std::max(c - 2 * kHalo, 0)]);
+    }
+    const int capacity = (int)(most * 3 / 2 + outside + 4096);
+    const int record_cap = (int)(widest * 3 / 2 + 4096);
+    int ndev = 1, dev0 = 0;
+    if (const char *e = std::getenv("FSA_SLAB_DEVICES")) ndev = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("FSA_DEVICE")) dev0 = std::atoi(e);
+    for (int r = 0; r < nslabs; r++) {
+        int h[2];
+        held(r, h);
+        fsa_params P = hParam;
+        P.slab_z0 = h[0];
+        P.slab_nz = h[1] - h[0];
+        fsa_solver *s = nullptr;
+        check(fsa_create(&P, FSA_PRECISION_F32, capacity, dev0 + r % ndev, &s), "fsa_create (slab)");
+        slab_devices.push_back(s);
+        vecf3 sp, sv;
+        vecf sm, srd;
+        veci st, sid;
+        for (int i = 0; i < n; i++) {
+            const bool mine = (layer[i] >= slab_cuts[r] && layer[i] < slab_cuts[r + 1]) || (r == 0 && layer[i] < 0);
+            if (!mine) continue;
+            sp.push_back(p[i]);
+            sv.push_back(v[i]);
+            sm.push_back(m[i]);
+            srd.push_back(rd[i]);
+            st.push_back(t[i]);
+            sid.push_back(i);
+        }
+        check(fsa_upload(s, (int)sp.size(), sp.data(), sv.data(), nullptr, nullptr, st.data(), nullptr, sid.data(),
+                         sm.data(), srd.data()),
+              "fsa_upload (slab)");
+        check(fsa_set_scene_has_rigid(s, 0), "fsa_set_scene_has_rigid");
+    }
+    check(fsa_slab_group_create_local(nslabs, slab_devices.data(), slab_cuts.data(), kHalo, record_cap, &slab_group),
+          "fsa_slab_group_create_local");
+    std::printf("%d particles on %d z-slabs (cuts", n, nslabs);
+    for (int c : slab_cuts) std::printf(" %d", c);
+    std::printf("), capacity %d each\n", capacity);
+}
+
+void SPHSolver::StepSlabs() { check(fsa_slab_group_step(slab_group, 1), "fsa_slab_group_step"); }
+
+// Positions and colours of all slabs in the order a single solver would hold them: ascending global cell, inside a
+// cell the slab's own order, out-of-grid particles last.
+void SPHSolver::CopyPosColorFromSlabs() {
+    fsa_slab_group_stats st{};
+    check(fsa_slab_group_sync(slab_group, &st), "fsa_slab_group_sync");
+    struct Item {
+        unsigned long long cell;
+        cfloat3 pos;
+        int id;
+    };
+    std::vector<Item> items;
+    items.reserve((size_t)numParticles);
+    const unsigned gx = (unsigned)hParam.gridres[0], gzz = (unsigned)hParam.gridres[2];
+    for (size_t r = 0; r < slab_devices.size(); r++) {
+        fsa_solver *s = slab_devices[r];
+        int n = 0;
+        check(fsa_num_particles(s, &n), "fsa_num_particles");
+        vecf3 p((size_t)n);
+        veci id((size_t)n), hash((size_t)n);
+        check(fsa_get_buffer(s, "pos", p.data(), (size_t)n * sizeof(cfloat3)), "get pos");
+        check(fsa_get_buffer(s, "uniqueId", id.data(), (size_t)n * sizeof(int)), "get uniqueId");
+        check(fsa_get_buffer(s, "particleHash", hash.data(), (size_t)n * sizeof(int)), "get particleHash");
+        const int z0 = std::max(slab_cuts[r] - kHalo, 0);
+        const unsigned nz = (unsigned)(std::min(slab_cuts[r + 1] + kHalo, (int)gzz) - z0);
+        for (int i = 0; i < n; i++) {
+            const unsigned h = (unsigned)hash[i];
+            if (h == kUndef) {
+                items.push_back({~0ull, p[i], id[i]});
+                continue;
+            }
+            const unsigned x = h % gx, t = h / gx, lz = t % nz, y = t / nz;
+            const int z = (int)lz + z0;
+            if (z < slab_cuts[r] || z >= slab_cuts[r + 1]) continue;  // a halo copy
+            items.push_back({((unsigned long long)y * gzz + (unsigned)z) * gx + x, p[i], id[i]});
+        }
+    }
+    if ((int)items.size() != numParticles) {
+        std::fprintf(stderr, "slab read-back: %zu particles owned, %d expected (%lld lost)\n", items.size(), numParticles,
+                     st.lost);
+        std::exit(EXIT_FAILURE);
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cell < b.cell; });
+    for (int i = 0; i < numParticles; i++) {
+        pos[i] = items[i].pos;
+        color[i] = slab_color[(size_t)items[i].id];
+    }
+}

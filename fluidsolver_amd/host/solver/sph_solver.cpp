@@ -11,6 +11,7 @@ void SPHSolver::check(int rc, const char *what) {
 }
 
 SPHSolver::~SPHSolver() {
+    LeaveSlabMode();
     if (device) fsa_destroy(device);
 }
 
@@ -59,12 +60,20 @@ void SPHSolver::CopyParam2Device() { check(fsa_copy_param_to_device(device, &hPa
 
 // CopyPosColorFromDevice, solver/sph_solver.cpp:35-38: current device order.
 void SPHSolver::CopyPosColorFromDevice() {
+    if (slab_group) {
+        CopyPosColorFromSlabs();
+        return;
+    }
     int n = 0;
     check(fsa_readback_pos_color(device, pos.data(), color.data(), &n), "fsa_readback_pos_color");
 }
 
 // CopySimulationDataFromDevice (solver/MultiphaseSPHSolver.cpp:29-46): everything the text dump prints.
 void SPHSolver::CopySimulationDataFromDevice() {
+    if (slab_group) {
+        std::fprintf(stderr, "dumps need velocities, groups and v_star in one place: not available with FSA_SLABS\n");
+        std::exit(EXIT_FAILURE);
+    }
     const size_t n = (size_t)numParticles;
     check(fsa_get_buffer(device, "pos", pos.data(), n * sizeof(cfloat3)), "get pos");
     check(fsa_get_buffer(device, "vel", vel.data(), n * sizeof(cfloat3)), "get vel");
@@ -113,7 +122,9 @@ void SPHSolver::SolveIISPH() {
 
 // Step, solver/sph_solver.cpp:129-142 and solver/MultiphaseSPHSolver.cpp:199-217
 void SPHSolver::Step() {
-    if (numParticles > 0) {
+    if (numParticles > 0 && slab_group) {
+        StepSlabs();
+    } else if (numParticles > 0) {
         switch (run_mode) {
         case SPH:
             SolveSPH();

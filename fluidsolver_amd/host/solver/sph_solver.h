@@ -33,6 +33,11 @@ protected:
     vecf3 v_star;
 
     fsa_solver *device = nullptr;  // replaces SimData_SPH device_data
+    // FSA_SLABS=N (slab_mode.cpp): the scene on N z-slab solvers driven as one group, `device` released
+    std::vector<fsa_solver *> slab_devices;
+    fsa_slab_group *slab_group = nullptr;
+    std::vector<int> slab_cuts;
+    vecf4 slab_color;  // colours by slab id
     fsa_params hParam{};           // replaces the global hParam (solver/sph_kernel_impl.cuh:13)
     // parameters of the scene file the device step does not use
     int maxpnum = 0;
@@ -75,6 +80,11 @@ public:
     void SolveIISPH();
 
     int AddDefaultParticle();
+
+    void EnterSlabMode(int nslabs);
+    void LeaveSlabMode();
+    void StepSlabs();
+    void CopyPosColorFromSlabs();
 
     virtual void DumpSimulationDataText();
     virtual void DumpRenderData();

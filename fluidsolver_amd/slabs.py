@@ -544,33 +544,97 @@ def _bench_distributed(args, build_scene):
     sc = build_scene(args.scene, args.jitter)
     n, n_fluid = len(sc["pos"]), sc["n_fluid"]
     transport = NeighbourTransport(rank, world, device, group=record_group)
+    # With a GPU per rank the step runs in the library's slab group: pack, ncclSend / ncclRecv, unpack and the
+    # solver's step queued without a host round trip.  Ranks sharing a card (rehearsal) keep the torch transport.
+    native = use_nccl and os.environ.get("FSA_SLAB_NATIVE", "1") != "0" and \
+        not bool((np.asarray(sc["type"]) == 4).any()) and (args.variant is None or args.variant == 3)
     ss = SlabSolver(sc, rank, world, transport,
-                    lambda P, held, cap: HipSlabBackend(P, held, cap, device_index, args.variant))
+                    lambda P, held, cap: HipSlabBackend(P, held, cap, device_index, args.variant),
+                    exchange_buffers=not native)
+    del sc
     sync_dev = torch.device("cpu")
+    from . import capi
+
+    def make_group():
+        uid = [capi.SlabGroup.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        return capi.SlabGroup.rccl(ss.backend.solver, rank, world, uid[0], ss.layout.cuts, ss.halo, ss.record_cap)
+
+    group = make_group() if native else None
+    recut_every = getattr(args, "recut_every", 0) or 0
+
+    def run(nsteps):
+        nonlocal group
+        done = 0
+        while done < nsteps:
+            k = nsteps - done
+            if recut_every:
+                k = min(k, recut_every - (run.total % recut_every))
+            if native:
+                group.step(k)
+            else:
+                ss.step(k)
+            done += k
+            run.total += k
+            if recut_every and run.total % recut_every == 0:
+                if native:
+                    st = group.sync()
+                    run.lost += int(st.lost)
+                    run.sent += int(st.records_sent)
+                    group.close()
+                timing = ss.backend.solver.timing_read() if run.timing else None
+                ss.rebalance()
+                if run.timing:  # the re-cut builds a new solver: carry the kernel times over
+                    for name, (c, ms) in timing.items():
+                        c0, m0 = run.kernels.get(name, (0, 0.0))
+                        run.kernels[name] = (c0 + c, m0 + ms)
+                    ss.backend.solver.timing_enable(True)
+                    ss.backend.solver.timing_reset()
+                if native:
+                    group = make_group()
+    run.total, run.lost, run.sent, run.timing, run.kernels = 0, 0, 0, False, {}
 
     def barrier():
+        if native:
+            group.sync()
         torch.cuda.synchronize()
         t = torch.zeros(1, device=sync_dev)
         dist.all_reduce(t)
         torch.cuda.synchronize()
 
-    ss.step(args.spinup)
-    ss.step(args.warmup)
+    run(args.spinup)
+    run(args.warmup)
+    barrier()
     ss.backend.solver.timing_enable(True)
     ss.backend.solver.timing_reset()
-    sent0 = ss.sent_records
+    run.timing = True
+    recuts0, sent0 = ss.recuts, ss.sent_records
+    if native:
+        run.sent = -int(group.sync().records_sent)
+    host_waits0 = capi.load().fsa_debug_host_waits()
     barrier()
     t0 = time.perf_counter()
-    ss.step(args.steps)
+    run(args.steps)
+    host_waits = capi.load().fsa_debug_host_waits() - host_waits0
     barrier()
     wall = time.perf_counter() - t0
     kt = ss.backend.solver.timing_read()
+    for name, (c, ms) in run.kernels.items():
+        c0, m0 = kt.get(name, (0, 0.0))
+        kt[name] = (c0 + c, m0 + ms)
     ss.backend.solver.timing_enable(False)
+    if native:
+        st = group.sync()
+        lost = run.lost + int(st.lost)
+        sent = run.sent + int(st.records_sent)
+    else:
+        lost, sent = ss.lost, ss.sent_records - sent0
     local_n = ss.backend.n
     types = ss.backend.get("type")
     local_fluid = int((types == 0).sum())
-    stats = torch.tensor([wall, float(local_n), float(ss.lost), float(ss.backend.solver.num_undef()),
-                          float(ss.sent_records - sent0)], dtype=torch.float64, device=sync_dev)
+    exch_ms = sum(ms for k, (c, ms) in kt.items() if k in ("slab_pack", "exchange", "slab_unpack")) / max(args.steps, 1)
+    stats = torch.tensor([wall, float(local_n), float(lost), float(ss.backend.solver.num_undef()), float(sent),
+                          exch_ms, float(host_waits)], dtype=torch.float64, device=sync_dev)
     mx = stats.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone()
@@ -578,8 +642,14 @@ def _bench_distributed(args, build_scene):
     res = dict(n=n, n_fluid=n_fluid, wall=float(mx[0]), kernels=kt, num_cells=ss.backend.params.num_cells,
                n_undef=int(sm[3]), gridres=list(ss.gridres), local_n=local_n, local_n_fluid=local_fluid,
                slab_cuts=ss.layout.cuts, halo_layers=ss.layout.halo, max_local_particles=int(mx[1]),
-               sum_local_particles=int(sm[1]), lost_particles=int(sm[2]),
-               records_sent_per_step=float(sm[4]) / max(args.steps, 1), comm_backend=backend)
+               mean_local_particles=float(sm[1]) / world, sum_local_particles=int(sm[1]), lost_particles=int(sm[2]),
+               records_sent_per_step=float(sm[4]) / max(args.steps, 1), comm_backend=backend,
+               slab_step="library slab group (RCCL send/recv, no host round trip)" if native else
+                         "torch.distributed transport, two host round trips per step",
+               exchange_ms_per_step_max=float(mx[5]), host_syncs_in_timed_steps=int(mx[6]),
+               recuts=ss.recuts - recuts0, recut_every=recut_every)
+    if native:
+        group.close()
     ss.close()
     dist.barrier()
     dist.destroy_process_group()

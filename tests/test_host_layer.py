@@ -193,6 +193,24 @@ def test_text_checkpoint_resume(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not have_bins(), reason="host layer not built")
+@pytest.mark.parametrize("slabs", [2, 3])
+def test_headless_program_on_slabs_equals_single_solver(tmp_path, slabs):
+    """FSA_SLABS=N: the same host program, the scene on N z-slab solvers driven as one group of the library (all on
+    the one GPU here): positions and colours of every frame's read-back are those of the single-solver run, byte for
+    byte"""
+    exe = os.path.join(HOST, "bin", "particle_solver")
+    e = env_for(20)
+    a, b = tmp_path / "single.bin", tmp_path / "slabs.bin"
+    subprocess.check_call([exe, "--frames", "15", "--save-final", str(a)], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    r = subprocess.run([exe, "--frames", "15", "--save-final", str(b)], env=dict(e, FSA_SLABS=str(slabs)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert f"on {slabs} z-slabs" in r.stdout
+    assert a.read_bytes() == b.read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
 def test_corrupted_checkpoint_is_refused(tmp_path):
     """ids outside 0 .. n-1, repeated ids, a particle count far beyond the file and a truncated file: each must end
     in "malformed checkpoint" and leave the set-up scene running, not write through a bad index"""

@@ -69,6 +69,28 @@ def test_local_group_lopsided_cuts_and_stepwise_sync():
         ss.close()
 
 
+def test_group_steps_make_no_host_synchronisation():
+    """queueing steps must not make the host wait for the stream or the device, not even once (the library counts
+    its own waits); all it may do is wait for an event recorded three steps earlier, which keeps the host from
+    running further ahead while the device still has work queued"""
+    lib = capi.load()
+    sc = SCENES["ddam"]()
+    ranks = make_ranks(sc, 3)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    g.step(5)
+    g.sync()
+    before = lib.fsa_debug_host_waits()
+    g.step(60)
+    assert lib.fsa_debug_host_waits() == before
+    st = g.sync()
+    assert lib.fsa_debug_host_waits() > before  # the sync itself is one
+    assert st.steps == 65 and st.lost == 0 and st.error_bits == 0
+    g.close()
+    for ss in ranks:
+        ss.close()
+
+
 def test_group_reports_an_outgrown_message():
     sc = SCENES["dam"]()
     ranks = make_ranks(sc, 2)
