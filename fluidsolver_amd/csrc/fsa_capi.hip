@@ -106,6 +106,7 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.rows = nullptr;
     d.big = nullptr;
     d.count = nullptr;
+    d.halt = nullptr;
 }
 
 void make_dev_params(const fsa_params &h, DevParams<float> &d) { to_dev_params(h, d); }
@@ -1078,22 +1079,23 @@ int fsa_iisph_solve_pressure(fsa_solver *hs, int maxiter, int *rounds, double *l
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
     if (maxiter < 0) return fail(FSA_ERR_INVALID, "maxiter < 0");
-    double err_sum = 0.0;
-    int done = 0;
-    const bool f32 = s->precision == FSA_PRECISION_F32;
-    for (int iter = 0; iter < maxiter; iter++) {
-        TRY(fsa_iisph_calc_dijpjl(hs));
-        TRY(fsa_iisph_calc_new_pressure(hs));
-        done++;
-        const double last = err_sum;
-        TRY(launch_mean_error(s, &err_sum));
-        // solver/sph_solver.cu:1440: both tests on float values
-        const double a = std::fabs(err_sum);
-        const double b = f32 ? (double)std::fabs((float)err_sum - (float)last) : std::fabs(err_sum - last);
-        if (a < 1e-6 || b < 1e-6) break;
+    // All rounds are queued at once; the stop test of solver/sph_solver.cu:1440 runs on the device after each
+    // round's mean, and once it has fired the remaining rounds' kernels return at their first instruction.  One
+    // read-back at the end tells how many rounds ran (each swaps the two pressure arrays).
+    TRY(launch_iisph_rounds_begin(s));
+    int rc = FSA_OK;
+    for (int iter = 0; iter < maxiter && !rc; iter++) {
+        rc = fsa_iisph_calc_dijpjl(hs);
+        if (!rc) rc = fsa_iisph_calc_new_pressure(hs);
+        if (!rc) rc = launch_iisph_round_end(s);
     }
+    int done = 0;
+    double mean = 0.0;
+    const int rc2 = launch_iisph_rounds_finish(s, maxiter, &done, &mean);
+    if (rc) return rc;
+    if (rc2) return rc2;
     if (rounds) *rounds = done;
-    if (last_mean) *last_mean = err_sum;
+    if (last_mean) *last_mean = mean;
     return FSA_OK;
 }
 

@@ -66,6 +66,9 @@ template <typename T> struct DevParams {
     // with every exchange) and the kernels of the step read it from here instead of taking their argument, which is
     // then only an upper bound the grid was sized for.  Null otherwise.
     const int *count;
+    // Iterations whose stop test lives on the device (the IISPH pressure rounds): the rounds are all queued at
+    // once, and a pass kernel returns at the start when this word is set (null: never).
+    const int *halt;
 };
 
 template <typename T> __device__ __forceinline__ int live_count(const DevParams<T> &P, int n) {

@@ -12,6 +12,7 @@
 // Every pass is a policy run by the kernels of fsa_pass.h.  Arithmetic follows the reference text
 // operation for operation (explicit casts where its double literals promote a float expression).
 #include <cstdlib>
+#include <cstring>
 
 #include "fsa_pass.h"
 
@@ -827,6 +828,91 @@ int launch_mean_error(Solver *s, double *out) {
     FSA_HIP(counted_stream_sync(s->stream));
     const double mean = sum / (double)n;
     *out = s->precision == FSA_PRECISION_F32 ? (double)(float)mean : mean;
+    return FSA_OK;
+}
+
+// ---- the pressure rounds with the stop test on the device -------------------------------------------------
+// State behind the partial sums in reduce_tmp: {last mean, mean} as doubles, then {rounds done, stop} as ints.
+constexpr int kRoundState = kSumBlocks + 8;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void halted_block_sum_kernel(int n, const T *__restrict__ in, double *__restrict__ out,
+                                                                  const int *__restrict__ halt) {
+    if (*halt) return;
+    __shared__ double part[kBlock / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) acc += (double)in[i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) acc += part[w];
+        out[blockIdx.x] = acc;
+    }
+}
+
+// One block: folds the partial sums in the order of block_sum_kernel, takes the mean, applies the two tests of
+// solver/sph_solver.cu:1440 (|mean| < 1e-6, |mean - last mean| < 1e-6, on values of the solver's precision).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void iisph_round_end_kernel(int n, int nb, double *__restrict__ tmp) {
+    double *st = tmp + kRoundState;
+    int *ist = reinterpret_cast<int *>(st + 2);
+    if (ist[1]) return;
+    __shared__ double part[kBlock / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kBlock) acc += tmp[i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) acc += part[w];
+        const double m = acc / (double)n;
+        const double mean = sizeof(T) == 4 ? (double)(float)m : m, last = st[1];
+        const double a = fabs(mean);
+        const double b = sizeof(T) == 4 ? (double)fabsf((float)mean - (float)last) : fabs(mean - last);
+        st[0] = last;
+        st[1] = mean;
+        ist[0] += 1;
+        if (a < 1e-6 || b < 1e-6) ist[1] = 1;
+    }
+}
+
+int launch_iisph_rounds_begin(Solver *s) {
+    double *tmp = (double *)s->b.reduce_tmp;
+    FSA_HIP(hipMemsetAsync(tmp + kRoundState, 0, 4 * sizeof(double), s->stream));
+    s->pf.halt = s->pd.halt = reinterpret_cast<const int *>(tmp + kRoundState + 2) + 1;
+    return FSA_OK;
+}
+
+int launch_iisph_round_end(Solver *s) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "mean_error");
+    const int n = s->n, nb = std::min(kSumBlocks, blocks_for(n));
+    double *tmp = (double *)s->b.reduce_tmp;
+    if (s->precision == FSA_PRECISION_F32) {
+        hipLaunchKernelGGL(halted_block_sum_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, n,
+                           (const float *)s->b.error, tmp, s->pf.halt);
+        hipLaunchKernelGGL(iisph_round_end_kernel<float>, dim3(1), dim3(kBlock), 0, s->stream, n, nb, tmp);
+    } else {
+        hipLaunchKernelGGL(halted_block_sum_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, n,
+                           (const double *)s->b.error, tmp, s->pf.halt);
+        hipLaunchKernelGGL(iisph_round_end_kernel<double>, dim3(1), dim3(kBlock), 0, s->stream, n, nb, tmp);
+    }
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_iisph_rounds_finish(Solver *s, int launched, int *done, double *mean) {
+    s->pf.halt = s->pd.halt = nullptr;
+    double st[3] = {0, 0, 0};
+    FSA_HIP(hipMemcpyAsync(st, (const double *)s->b.reduce_tmp + kRoundState, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
+    int ist[2];
+    std::memcpy(ist, &st[2], sizeof(ist));
+    *done = s->n == 0 ? 0 : ist[0];
+    *mean = st[1];
+    // every queued round swapped the two pressure arrays on the host; the ones that did not run must not count
+    if (s->n > 0 && ((launched - ist[0]) & 1)) std::swap(s->b.pressure, s->b.pressure_alt);
     return FSA_OK;
 }
 

@@ -83,6 +83,7 @@ __device__ __forceinline__ void generic_walk(const DevParams<T> &P, const PassAr
 template <typename T, typename Policy>
 __global__ __launch_bounds__(kBlock) void generic_pass_kernel(DevParams<T> P, int n, PassArrays<T> A,
                                                               const int *__restrict__ cellStart) {
+    if (P.halt && *P.halt) return;  // see DevParams::halt
     const int index = blockIdx.x * kBlock + threadIdx.x;
     if (index >= n) return;
     const Vec4<T> pi = A.posType[index];
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
     using Shared = RowShared<BS, ROWCAP, true>;
     __shared__ Shared sh;
     __shared__ unsigned short queue[(Q + 2 * kDrainBatch) * BS];  // the drain reads ahead of the last entry
+    if (P.halt && *P.halt) return;  // see DevParams::halt
     const int tid = threadIdx.x;
     const int blk = tile_block<ROWCAP>(P, xcd_log);
     if (blk < 0) return;
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
                                                        const unsigned short *__restrict__ counts, int xcd_log) {
     __shared__ int rowStartG[16];  // 9 used
     __shared__ int stagedFlag;
+    if (P.halt && *P.halt) return;  // see DevParams::halt
     const int tid = threadIdx.x;
     const int b0 = xcd_block(xcd_log) * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid

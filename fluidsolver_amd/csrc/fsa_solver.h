@@ -199,6 +199,9 @@ int launch_iisph_new_pressure(Solver *s);
 int launch_iisph_pressure_force(Solver *s);
 int launch_iisph_integrate(Solver *s);
 int launch_mean_error(Solver *s, double *out);  // synchronises
+int launch_iisph_rounds_begin(Solver *s);  // the pressure rounds with their stop test on the device ...
+int launch_iisph_round_end(Solver *s);     // ... mean of error[] and the test, after each round
+int launch_iisph_rounds_finish(Solver *s, int launched, int *done, double *mean);  // synchronises once
 int ensure_lists(Solver *s);  // builds the neighbour lists if they are enabled and stale
 int launch_density_tuned(Solver *s);
 int launch_density_fast(Solver *s);

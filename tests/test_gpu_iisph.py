@@ -133,6 +133,54 @@ def test_pressure_solve_rounds_and_result(pair):
     assert rel_err(s.get("pressure")[fluid], st["pressure"][fluid]) <= 100 * tol
 
 
+@pytest.mark.parametrize("maxiter", [1, 2, 3, 7])
+def test_pressure_solve_round_limits(pair, maxiter):
+    """the rounds are queued at once and each swaps the two pressure arrays: whatever the number of rounds, asked for
+    or run, "pressure" must be the array the last round wrote"""
+    sc, p, st, s, tol, variant = pair
+    setup_both(p, st, s)
+    st.non_pressure_force_multiphase(p)
+    s.non_pressure_force_multiphase()
+    st.iisph_predict_density(p)
+    s.iisph_predict_density()
+    r_o, m_o = st.iisph_solve_pressure(p, maxiter, mean_in_double=True)
+    r_g, m_g = s.iisph_solve_pressure(maxiter)
+    assert r_g == r_o
+    fluid = st["type"] == 0
+    assert rel_err(s.get("pressure")[fluid], st["pressure"][fluid]) <= 100 * tol
+
+
+def test_pressure_solve_stops_on_the_device(orc32):
+    """particles too far apart to see each other: the mean of error[] is the same in every round, so the loop stops
+    in its second round while ten were queued; rounds, mean and the pressure array must be the oracle's"""
+    sc = scenes.iisph_tank(6, 6, 6, wall_group=1, fluid_groups=(0,))
+    sc = dict(sc)
+    fluid = sc["type"] == 0
+    centre = sc["pos"][fluid].mean(0)
+    pos = sc["pos"].copy()
+    pos[fluid] = centre + (pos[fluid] - centre) * np.float32(2.6)  # 2.6 spacings apart > the support of 2
+    sc["pos"] = pos
+    p, st = oracle_pair(orc32, sc)
+    _, s = gpu_solver(sc)
+    setup_both(p, st, s)
+    st.non_pressure_force_multiphase(p)
+    s.non_pressure_force_multiphase()
+    st.iisph_predict_density(p)
+    s.iisph_predict_density()
+    r_o, m_o = st.iisph_solve_pressure(p, 10, mean_in_double=True)
+    r_g, m_g = s.iisph_solve_pressure(10)
+    assert r_o < 10, "the scene was meant to stop the loop early"
+    assert r_g == r_o
+    assert abs(m_g - m_o) <= 1e-4 * max(abs(m_o), 1e-12)
+    fl = st["type"] == 0
+    assert rel_err(s.get("pressure")[fl], st["pressure"][fl]) <= 1e-4
+    s.iisph_update()  # reads the array the last round wrote
+    st.iisph_update(p)
+    assert rel_err(s.get("vel"), st["vel"]) <= 1e-4
+    s.close()
+    st.close()
+
+
 def test_five_iisph_steps(pair):
     sc, p, st, s, tol, variant = pair
     setup_both(p, st, s)
