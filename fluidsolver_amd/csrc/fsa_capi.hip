@@ -138,7 +138,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.blockLo, b.blockHi, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.blockLo, b.blockHi, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.wallCount, b.wallList, b.wallForce, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters, b.slabVars};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -338,6 +338,9 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     if (precision == FSA_PRECISION_F32) {  // recorded hits of the WCSPH passes (fsa_sph_fast.hip)
         ALLOC(b.hitWords, (nblocks + 8) * kHitSlots * kTunedBS * 8, false);
         ALLOC(b.hitCount, (nblocks + 8) * kTunedBS, true);
+        ALLOC(b.wallCount, (nblocks + 8) * kTunedBS, true);
+        ALLOC(b.wallList, (N + 8) * sizeof(int), true);
+        ALLOC(b.wallForce, (N + 8) * 4 * sizeof(float), false);
     }
     ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
     ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);

@@ -64,6 +64,9 @@ struct Buffers {
     unsigned short *nbCount = nullptr;  // entries per particle
     void *hitWords = nullptr;           // recorded hits of the WCSPH passes (fp32), see fsa_tile.h
     unsigned char *hitCount = nullptr;  // words per particle
+    unsigned char *wallCount = nullptr; // wall words per particle
+    int *wallList = nullptr;            // [0] = count, then the particles that have wall words
+    void *wallForce = nullptr;          // float4 per particle: the wall pass's sum (read where wallCount > 0)
     int *scanTmp = nullptr;
     int *undefBlockCount = nullptr;
     int *undefBlockStart = nullptr;

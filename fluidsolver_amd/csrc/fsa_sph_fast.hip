@@ -44,6 +44,8 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                                                             const int *__restrict__ sortedHash,
                                                             uint2 *__restrict__ hitWords,
                                                             unsigned char *__restrict__ hitCount,
+                                                            unsigned char *__restrict__ wallCount,
+                                                            int *__restrict__ wallList,
                                                             float *__restrict__ density,
                                                             float *__restrict__ pressure,
                                                             float2 *__restrict__ pd, int run_log) {
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
     const float inv_h = 1.0f / h, kcubic = P.kernel_cubic;
     float dens = 0.f;
     int words = kHitOverflow;  // an untiled block: the force pass walks the cells for its particles, too
+    int wwords = 0;            // wall words of the record
     if (!staged) {
         if (EVAL && active) dens = density_walk_global_fast(P, pi, mass_i, posType, cellStart);
     } else {
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
         float *const q = queue + (EVAL ? tid : 0);
         int cnt = 0;  // entries in the queue
         words = 0;
+        wwords = 0;
         auto drain = [&]() {
             if (dbg & 2) { cnt = 0; return; }
             for (int s = 0; wave_any(s < cnt); s += kChunk) {
@@ -311,7 +315,11 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                         if (le - c0 < 32) bits &= (1u << (le - c0)) - 1u;
                         m = __brev(bits);  // first candidate highest
                     }
-                    put_word(m, kHitWallFlag | ((unsigned)r << kHitSegShift) | (unsigned)c0);
+                    if (m) {  // a wall word: where its first candidate is in the sorted arrays
+                        if (wwords < kHitWall && !(dbg & 1))
+                            out[(size_t)(kMaxSegs + kHitExtra + wwords) * BS] = make_uint2(m, (unsigned)(sg.start[r] + c0));
+                        wwords++;
+                    }
                 }
             }
             if (r + 1 < nseg) {
@@ -321,10 +329,24 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
             }
         }
         if (EVAL) drain();
-        if (words > kHitExtra) words = kHitOverflow;
+        if (words > kHitExtra || wwords > kHitWall) words = kHitOverflow;
+        if (words == kHitOverflow) wwords = 0;
+    }
+    // particles with wall neighbours are listed for the wall pass (any order: they are independent)
+    {
+        const bool listed = active && wwords > 0;
+        const unsigned long long m = __ballot(listed);
+        if (m) {
+            const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(wallList, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (listed) wallList[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = index;
+        }
     }
     if (active) {
         hitCount[index] = (unsigned char)words;
+        wallCount[index] = (unsigned char)wwords;
         if (EVAL) {
             density[index] = dens;
             float pr = P.pressureK * (r_pow(dens / rd_i, 7.0f) - 1);
@@ -333,6 +355,49 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
             // the per-particle terms of the force pass, while they are at hand
             pd[index] = make_float2(pr / dens / dens, mass_i / dens * 2.0f * P.viscosity);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wall pass: the TYPE_BOUNDARY neighbours of the listed particles, one particle per lane
+// ------------------------------------------------------------------------------------------------
+// A fluid particle in contact with a wall has dozens of wall neighbours (every wall particle of its 27 cells counts)
+// while the particles around it have none; replayed inside the force pass they made their whole wavefront wait.
+// Here every lane is such a particle.  Sums in neighbour order, into wallForce[i], which the force pass adds.
+template <int BS>
+__global__ __launch_bounds__(256) void wall_force_kernel(DevParams<float> P, const int *__restrict__ wallList,
+                                                         const float4 *__restrict__ posType,
+                                                         const float4 *__restrict__ velMass,
+                                                         const uint2 *__restrict__ hitWords,
+                                                         const unsigned char *__restrict__ wallCount,
+                                                         float4 *__restrict__ wallForce) {
+    const int count = wallList[0];
+    const float sr = P.sr, sr2 = sr * sr;
+    const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+    const WallConsts W(P);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
+        const int i = wallList[1 + e];
+        ForceSelf<float> Sb;
+        Sb.p = posType[i];
+        Sb.v = velMass[i];
+        Sb.pterm = 0.f;
+        Sb.fx = Sb.fy = Sb.fz = 0.f;
+        const uint2 *wp = hitWords + (size_t)(i / BS) * kHitSlots * BS + (size_t)(kMaxSegs + kHitExtra) * BS + (i % BS);
+        const int words = wallCount[i];
+        for (int k = 0; k < words; k++) {
+            const uint2 w = wp[(size_t)k * BS];
+            unsigned m = w.x;
+            while (m) {
+                const int b = __builtin_clz(m);
+                m &= ~(0x80000000u >> b);
+                const int j = (int)w.y + b;
+                const float4 pj = posType[j], vj = velMass[j];
+                const float xx = Sb.p.x - pj.x, xy = Sb.p.y - pj.y, xz = Sb.p.z - pj.z;
+                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, true, vj.w, vj.x, vj.y, vj.z);
+            }
+        }
+        wallForce[i] = make_float4(Sb.fx, Sb.fy, Sb.fz, 0.f);
     }
 }
 
@@ -361,6 +426,8 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
                                                         const int *__restrict__ sortedHash,
                                                         const uint2 *__restrict__ hitWords,
                                                         const unsigned char *__restrict__ hitCount,
+                                                        const unsigned char *__restrict__ wallCount,
+                                                        const float4 *__restrict__ wallForce,
                                                         Vec3<float> *__restrict__ force, int run_log) {
     using Shared = RowShared<1, 4, false>;  // only its row table is used here
     __shared__ Shared sh;
@@ -415,14 +482,13 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
     if (!rec) cnt = 0;
     if (staged) {
         const uint2 *const wp = hitWords + (size_t)blk * kHitSlots * BS + tid;
-        constexpr unsigned kNoSeg = 0x7fffu;
+        constexpr unsigned kNoSeg = 0xffffu;
         auto extra_at = [&](int k) { return k < cnt ? wp[(size_t)(kMaxSegs + k) * BS] : make_uint2(0u, kNoSeg << kHitSegShift); };
         int xk = 0;                 // extra words taken so far
         uint2 xw = extra_at(0);     // the next one
         unsigned cur = 0, pend = 0; // bits at hand (32 candidates from `cbase` on), and the 25 after them
         int cseg = -1;              // the segment they belong to
         int cbase = 0;              // tile entry of bit 31 of `cur`, the two tiles counted through
-        bool cwall = false;         // they are TYPE_BOUNDARY particles
         struct Stage {
             float4 p, v;
             float2 a;
@@ -466,7 +532,7 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
             uint2 fwn = make_uint2(0u, 0u);
             if (r + 1 < nseg && rec) fwn = wp[(size_t)(r + 1) * BS];  // in flight during this segment's loop
             struct Nb {
-                bool has, wall;
+                bool has;
                 int t;
                 float4 a, b;
                 float c;
@@ -479,14 +545,12 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
                             cur = pend;
                             pend = 0;
                             cbase += 32;
-                        } else if (((xw.y & ~kHitWallFlag) >> kHitSegShift) == (unsigned)cseg) {  // an extra word of this segment
+                        } else if ((xw.y >> kHitSegShift) == (unsigned)cseg) {  // an extra word of this segment
                             cur = xw.x;
-                            cwall = (xw.y & kHitWallFlag) != 0;
                             cbase = (cseg & 1) * ROWCAP + (int)(xw.y & ((1u << kHitSegShift) - 1u));
                             xw = extra_at(++xk);
                         } else if (cseg < r) {  // on to segment r, whose main word is `fw`
                             cseg = r;
-                            cwall = false;
                             cur = fw.x;
                             pend = fw.y & ~kHitMainMask;
                             cbase = (r & 1) * ROWCAP + 4 * (int)(fw.y & kHitMainMask);
@@ -506,7 +570,6 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
                     if (busy == 0ull || (r + 1 < nseg && __popcll(busy) < quorum)) return false;
                 }
                 N.has = has;
-                N.wall = has && cwall;
                 const int k = __builtin_clz(cur | 1u);  // cur == 0: nothing to clear
                 cur &= ~(0x80000000u >> k);
                 N.t = has ? cbase + k : 0;
@@ -520,10 +583,8 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
                 const float xx = S.p.x - N.a.x, xy = S.p.y - N.a.y, xz = S.p.z - N.a.z;
                 const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
                 // straight-line: a lane without a neighbour in this trip evaluates entry 0 and adds exact zeros
-                force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, N.has && !N.wall,
-                                make_float4(N.b.x, N.b.y, N.b.z, N.a.w), make_float2(N.b.w, N.c));
-                if (wave_any(N.wall))  // wall particles: summed apart
-                    wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, N.wall, N.a.w, N.b.x, N.b.y, N.b.z);
+                force_pair_fast(S, sr, kspiky, visc_eps, xx, xy, xz, d2, N.has, make_float4(N.b.x, N.b.y, N.b.z, N.a.w),
+                                make_float2(N.b.w, N.c));
             };
             // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated
             auto run = [&](int part) {
@@ -551,6 +612,12 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
         }
     }
     if (active) {
+        if (rec && wallCount[index] > 0) {  // the wall pass's sum for this particle
+            const float4 wf = wallForce[index];
+            Sb.fx = wf.x;
+            Sb.fy = wf.y;
+            Sb.fz = wf.z;
+        }
         Vec3<float> f;
         S.fx += Sb.fx;
         S.fy += Sb.fy;
@@ -574,11 +641,12 @@ static inline int tiled_grid(const Solver *s, int run_log) {
 
 template <bool EVAL> static int launch_density_record(Solver *s) {
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
+    FSA_HIP(hipMemsetAsync(s->b.wallList, 0, sizeof(int), s->stream));  // the list of the wall pass starts empty
     hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, run_log)),
                        dim3(kTunedBS), 0, s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c],
                        (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
-                       s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, (float *)s->b.density,
-                       (float *)s->b.pressure, (float2 *)s->b.pd, run_log);
+                       s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, s->b.wallCount, s->b.wallList,
+                       (float *)s->b.density, (float *)s->b.pressure, (float2 *)s->b.pd, run_log);
     FSA_HIP(hipGetLastError());
     s->hits_valid = true;
     return FSA_OK;
@@ -602,12 +670,18 @@ int launch_force_fast(Solver *s) {
         int rc = launch_density_record<false>(s);
         if (rc) return rc;
     }
-    ScopedTimer t(s, "force");
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
+    {
+        ScopedTimer t(s, "wall_force");
+        hipLaunchKernelGGL((wall_force_kernel<kTunedBS>), dim3(1024), dim3(256), 0, s->stream, s->pf, s->b.wallList,
+                           (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
+                           (const uint2 *)s->b.hitWords, s->b.wallCount, (float4 *)s->b.wallForce);
+    }
+    ScopedTimer t(s, "force");
     hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, run_log)), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                        (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
-                       s->b.hitCount, (Vec3<float> *)s->b.force, run_log);
+                       s->b.hitCount, s->b.wallCount, (const float4 *)s->b.wallForce, (Vec3<float> *)s->b.force, run_log);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

@@ -49,21 +49,25 @@ constexpr int kListOverflow = 0xffff;
 
 // Recorded hits of the WCSPH passes (fsa_sph_fast.hip), per block of kTunedBS particles as [slot][lane] (a
 // wavefront reads and writes 512 contiguous bytes per slot), kHitSlots 8-byte slots per particle:
-//   slot s < kMaxSegs : the main word of segment s, written for every segment the block has: a bit mask of the 57
-//                       candidates from group g0 of the segment's tile on (first candidate at bit 31 of .x, the 33rd at
-//                       bit 31 of .y) and g0 in the low kHitMainShift bits of .y;
-//   the slots after   : extra words in neighbour order, {32-candidate mask (first candidate highest), flags |
-//                       segment << kHitSegShift | first candidate's index in the tile}: what a lane's range holds
-//                       beyond 57 candidates, and TYPE_BOUNDARY neighbours (flagged kHitWallFlag), which count
-//                       wherever they are in the 27 cells.
-// hitCount = number of extra words, kHitOverflow for a particle without a record, which walks the cells instead.
+//   slot s < kMaxSegs       : the main word of segment s, written for every segment the block has: a bit mask of the
+//                             57 candidates from group g0 of the segment's tile on (first candidate at bit 31 of .x,
+//                             the 33rd at bit 31 of .y) and g0 in the low kHitMainShift bits of .y;
+//   the kHitExtra after     : extra words in neighbour order, {32-candidate mask (first candidate highest),
+//                             segment << kHitSegShift | first candidate's index in the tile}: what a lane's range
+//                             holds beyond 57 candidates;
+//   the kHitWall after that : TYPE_BOUNDARY neighbours, which count wherever they are in the 27 cells, in neighbour
+//                             order: {32-candidate mask, index of the first candidate in the sorted arrays}.  They are
+//                             not replayed from the tiles: particles that have any are listed (wallList) and a
+//                             pass of their own, where every lane is such a particle, sums their wall forces.
+// hitCount = number of extra words, kHitOverflow for a particle without a record, which walks the cells instead;
+// wallCount = number of wall words.
 constexpr int kMaxSegs = 18;  // a block's nine rows, the long ones as two tiles each (see Segments below)
-constexpr int kHitExtra = 14;
-constexpr int kHitSlots = kMaxSegs + kHitExtra;
+constexpr int kHitExtra = 6;
+constexpr int kHitWall = 14;
+constexpr int kHitSlots = kMaxSegs + kHitExtra + kHitWall;
 constexpr int kHitMainShift = 7;
 constexpr unsigned kHitMainMask = (1u << kHitMainShift) - 1u;
 constexpr int kHitOverflow = 255;
-constexpr unsigned kHitWallFlag = 0x80000000u;
 constexpr int kHitSegShift = 16;
 
 __device__ __forceinline__ void block_row(const DevParams<float> &P, unsigned hlo, unsigned hhi, bool grid_ok, int r,
