@@ -18,6 +18,7 @@
 #include <utility>
 
 #include "fsa_advect.h"
+#include "fsa_hash.h"
 #include "fsa_solver.h"
 #include "fsa_tile.h"
 
@@ -26,59 +27,6 @@ namespace fsa {
 // ------------------------------------------------------------------------------------------------
 // 1. hash + count
 // ------------------------------------------------------------------------------------------------
-// The hash and count of particle i at (x, y, z); every thread of the block calls it (`valid` = there is a particle).
-template <typename T>
-__device__ __forceinline__ void hash_and_count(const DevParams<T> &P, bool valid, int i, T x, T y, T z,
-                                               int *__restrict__ hash, int *__restrict__ slot,
-                                               int *__restrict__ cellCount, int *__restrict__ undefBlockCount,
-                                               int *waveCount /* shared, kBlock / 64 */) {
-    unsigned h = 0;
-    if (valid) {
-        if (!in_domain(P, x, y, z)) {
-            h = FSA_GRID_UNDEF;
-        } else {
-            int cx, cy, cz;
-            calc_grid_pos(P, x, y, z, cx, cy, cz);
-            h = calc_grid_hash(P, cx, cy, cz);
-        }
-        hash[i] = (int)h;
-    }
-    const bool undef = valid && h == FSA_GRID_UNDEF;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // One atomic per run of equal cells inside the wavefront instead of one per particle: after the
-    // first step the input is almost sorted, so a run is usually a whole cell.  The run leader adds the
-    // run length and hands the base to the others; the order inside a cell is settled later (rank).
-    int my = 0;
-    {
-        const bool counts = valid && !undef;
-        const unsigned hprev = (unsigned)__shfl_up((int)h, 1, 64);
-        const bool start = lane == 0 || !counts || h != hprev;
-        const unsigned long long starts = __ballot(start);
-        const unsigned long long upto = starts & ((2ull << lane) - 1ull);     // run starts at or below this lane
-        const unsigned long long above = starts & ~((2ull << lane) - 1ull);  // run starts above it
-        const int leader = 63 - __clzll((long long)upto);
-        const int next = above ? __ffsll((long long)above) - 1 : 64;
-        int base = 0;
-        if (counts && lane == leader) base = atomicAdd(&cellCount[h], next - leader);
-        base = __shfl(base, leader, 64);
-        if (counts) my = base + (lane - leader);
-    }
-    const unsigned long long m = __ballot(undef);
-    if (lane == 0) waveCount[wave] = __popcll(m);
-    __syncthreads();
-    if (undef) {
-        int base = 0;
-        for (int w = 0; w < wave; w++) base += waveCount[w];
-        my = base + __popcll(m & ((1ull << lane) - 1ull));
-    }
-    if (valid) slot[i] = my;
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < kBlock / 64; w++) tot += waveCount[w];
-        undefBlockCount[blockIdx.x] = tot;
-    }
-}
-
 // PosT: Vec4<T> ({x, y, z, type bits}, the solver's layout) or Vec3<T> (the reference's cfloat3 layout)
 template <typename T, typename PosT>
 __global__ __launch_bounds__(kBlock) void hash_count_kernel(DevParams<T> P, const PosT *__restrict__ posType,
@@ -465,6 +413,7 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, const int
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned h = (unsigned)hash[i];
+    if (h == kHashDrop) return;  // the particle has left this solver (fsa_hash.h)
     const int sl = slot[i];
     int p;
     if (h != FSA_GRID_UNDEF) {
@@ -490,6 +439,7 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, const int
 // every fluid particle before anybody can read it).
 // BY_KEY (z-slab solvers, fsa_slab.hip): ties inside a cell are broken by the 64-bit order key each particle
 // carries instead of by the source index, and the key of the new order is written on the way.
+// slots / undefBlockStart / count_out: see the start of the kernel (null for everything but z-slab groups).
 template <typename T, bool VSTAR_ALL, bool BY_KEY>
 __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
     DevParams<float> Pf, int n, const int *__restrict__ tmpIndex, const int *__restrict__ tmpHash,
@@ -499,9 +449,17 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
     Vec4<T> *__restrict__ velMassOut, T *__restrict__ restDensityOut, int *__restrict__ uniqueIdOut,
     Vec3<T> *__restrict__ vStarOut, const int *__restrict__ blockLo, const int *__restrict__ blockHi,
     int *__restrict__ table, int *__restrict__ big, const long long *__restrict__ keyIn,
-    long long *__restrict__ keyOut) {
+    long long *__restrict__ keyOut, const int *__restrict__ slots, const int *__restrict__ undefBlockStart,
+    int *__restrict__ count_out) {
     static_assert(kTunedBS == kBlock, "one row-table entry per block of this kernel");
-    n = live_count(Pf, n);
+    if (slots) {
+        // z-slab groups: the source arrays have `*slots` slots, some of them dropped; what the sort keeps is what
+        // the two prefix sums counted, and that becomes the particle count of the kernels that follow
+        n = cellStart[Pf.num_cells] + undefBlockStart[(*slots + kBlock - 1) / kBlock];
+        if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    } else {
+        n = live_count(Pf, n);
+    }
     if ((int)blockIdx.x * kBlock >= n) return;
     const int sIdx = blockIdx.x * kBlock + threadIdx.x;
     if (table && threadIdx.x < 64) {  // row table (fp32 solvers), as block_rows_kernel
@@ -534,8 +492,19 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
             if (cls == 2) big[1 + atomicAdd(&big[0], 1)] = blk;  // any order: the blocks are independent
         }
     }
+    // BY_KEY: the keys of the block's 256 entries go through LDS -- a cell's entries are consecutive, so nearly all
+    // the keys a thread compares its own with are there (a gather per comparison otherwise)
+    __shared__ unsigned long long keyS[BY_KEY ? kBlock : 1];
+    __shared__ int idxS[BY_KEY ? kBlock : 1];
+    const int i = sIdx < n ? tmpIndex[sIdx] : 0;
+    unsigned long long mine = 0;
+    if (BY_KEY) {
+        if (sIdx < n) mine = (unsigned long long)keyIn[i];
+        keyS[threadIdx.x] = mine;
+        idxS[threadIdx.x] = i;
+        __syncthreads();
+    }
     if (sIdx >= n) return;
-    const int i = tmpIndex[sIdx];
     const unsigned h = (unsigned)tmpHash[sIdx];
     int p = sIdx;  // out-of-grid particles are already in stable order
     int first = cellStart[Pf.num_cells];  // of the particle's cell (out of grid: of the tail)
@@ -543,10 +512,17 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
         const int a = cellStart[h], b = cellStart[h + 1];
         int r = 0;
         if (BY_KEY) {
-            const unsigned long long mine = (unsigned long long)keyIn[i];
+            const int b0 = blockIdx.x * kBlock;
             for (int t = a; t < b; t++) {
-                const int j = tmpIndex[t];
-                const unsigned long long other = (unsigned long long)keyIn[j];
+                int j;
+                unsigned long long other;
+                if (t >= b0 && t < b0 + kBlock) {
+                    j = idxS[t - b0];
+                    other = keyS[t - b0];
+                } else {
+                    j = tmpIndex[t];
+                    other = (unsigned long long)keyIn[j];
+                }
                 r += (other < mine || (other == mine && j < i)) ? 1 : 0;
             }
         } else {
@@ -692,8 +668,9 @@ int launch_hash_fused(Solver *s, bool with_advect) {
 // hash / slot / cellCount must describe the current arrays.  Leaves cellCount zeroed.
 int launch_sort_fused(Solver *s, bool vstar_all) {
     const int n = s->grid_n(), nb = blocks_for(n), C = s->num_cells;
+    const int *slots = s->slab_slots;  // z-slab groups: the number of source slots, on the device
     Scan2 a;
-    a.count = s->pf.count;
+    a.count = slots ? slots : s->pf.count;
     a.in[0] = s->b.cellCount;
     a.out[0] = s->b.cellStart;
     a.n[0] = C;
@@ -717,7 +694,7 @@ int launch_sort_fused(Solver *s, bool vstar_all) {
     if (n == 0) return FSA_OK;
     {
         ScopedTimer t(s, "scatter");
-        hipLaunchKernelGGL(scatter_bounds_kernel, dim3(nb), dim3(kBlock), 0, s->stream, n, s->pf.count, C, s->b.hash, s->b.slot,
+        hipLaunchKernelGGL(scatter_bounds_kernel, dim3(nb), dim3(kBlock), 0, s->stream, n, a.count, C, s->b.hash, s->b.slot,
                            s->b.cellStart, s->b.undefBlockStart, s->b.tmpIndex, s->b.tmpHash, s->b.blockLo,
                            s->b.blockHi);
     }
@@ -732,7 +709,8 @@ int launch_sort_fused(Solver *s, bool vstar_all) {
                        s->b.uniqueId[in], (const Vec3<T> *)s->b.v_star, (T4 *)s->b.posType[out],                    \
                        (T4 *)s->b.velMass[out], (T *)s->b.restDensity[out], s->b.uniqueId[out],                     \
                        (Vec3<T> *)s->b.v_star_alt, s->b.blockLo, s->b.blockHi, f32 ? s->b.blockRows : nullptr,      \
-                       s->b.bigBlocks, s->b.orderKey[in], s->b.orderKey[out])
+                       s->b.bigBlocks, s->b.orderKey[in], s->b.orderKey[out], slots, s->b.undefBlockStart,              \
+                       slots ? s->b.slabVars + kVarN : nullptr)
         if (s->slab) {
             if (f32) FSA_RR(float, float4, false, true); else FSA_RR(double, double4, false, true);
         } else if (f32) {

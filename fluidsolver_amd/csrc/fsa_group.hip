@@ -7,15 +7,18 @@
 // lives in device memory (DevParams::count), the pack and unpack kernels keep it and the message counts up to
 // date there, and launch grids are sized for the solver's capacity.
 //
-//   pack       particles owned at the last sort are sorted into stay / send left / send right (fsa_slab.hip); a
-//              one-thread kernel turns the atomic counters into the new particle count and the message headers;
+//   pack       one pass over the particles does the integration of the step before, decides by the new position who
+//              stays, who goes out as a record to the left or right neighbour and who is dropped (the halo copies of
+//              the step before), and computes the hash and cell counts of those that stay (fsa_slab.hip); nothing is
+//              moved, the sort gathers what is left.  A one-thread kernel turns the atomic counters into the message
+//              headers.  The pack of step k + 1 thus runs at the end of step k;
 //   transport  LOCAL: all slabs belong to solvers of this process (on one GPU or several): the send buffer is
 //              copied into the neighbour's receive buffer on the sender's stream, events order it against the
 //              neighbour's unpack of this step and of the step before;
 //              RCCL: one slab per process: ncclSend / ncclRecv to both z-neighbours in one group call on the
 //              solver's stream (xGMI between the GPUs of a node);
-//   unpack     records of both receive buffers are appended, the count is raised;
-//   then the ordinary hash -> sort -> density -> force -> integration of the solver.
+//   unpack     records of both receive buffers are appended and hashed, the number of slots is raised;
+//   then scan -> scatter -> rank + reorder (the particle count becomes what the sort kept) -> density -> force.
 //
 // Message sizes.  A send or copy needs its size on the host when it is queued, and the host does not know this
 // step's counts.  Both ends therefore size the message of step k from the count of step k - kLag, which each of
@@ -48,7 +51,8 @@ struct Member {
     char *recv[2] = {nullptr, nullptr};  // [0] from the left neighbour, [1] from the right
     int *mirror = nullptr;               // pinned host memory: kRing x kMirrorInts
     hipEvent_t ev_pack[kRing] = {}, ev_unpack[kRing] = {}, ev_sent[2] = {};
-    int size_out[2] = {0, 0};            // records this step's messages take
+    int size_out[2] = {0, 0};            // records the messages take that are packed (or were sent last)
+    bool packed = false;                 // the send buffers hold the next message (and the solver's hash is ahead)
 };
 
 struct Group {
@@ -93,7 +97,10 @@ static void free_member(Member &mb) {
             int n = mb.s->n;
             if (hipMemcpy(&n, mb.s->b.slabVars + kVarN, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) mb.s->n = n;
             mb.s->pf.count = mb.s->pd.count = nullptr;
+            mb.s->slab_slots = nullptr;
             mb.s->count_stale = false;
+            // hash[] may hold the marks of a pack whose message never went out
+            mb.s->hash_valid = mb.s->hash_ahead = false;
         }
     }
     for (int d = 0; d < 2; d++) {
@@ -150,16 +157,18 @@ static int setup_member(Group &g, Member &mb, Solver *s, int rank) {
     FSA_HIP(hipMemset(s->b.slabCounters, 0, 8 * sizeof(int)));
     FSA_HIP(counted_device_sync());
     s->pf.count = s->pd.count = s->b.slabVars + kVarN;
+    s->slab_slots = s->b.slabVars + kVarSlots;
+    s->hash_valid = s->hash_ahead = false;
     s->pf.own_lo = s->pd.own_lo = mb.own[0];
     s->pf.own_hi = s->pd.own_hi = mb.own[1];
     return FSA_OK;
 }
 
-// Sizes of this step's two outgoing messages of a member, from its own counts of kLag steps ago.
-static int outgoing_sizes(Group &g, Member &mb) {
+// Sizes of a member's two outgoing messages of step `msg`, from its own counts of kLag steps before.
+static int outgoing_sizes(Group &g, Member &mb, long long msg) {
     for (int d = 0; d < 2; d++) mb.size_out[d] = g.record_cap;
-    if (g.step >= kLag) {
-        const int slot = (int)((g.step - kLag) % kRing);
+    if (msg >= kLag) {
+        const int slot = (int)((msg - kLag) % kRing);
         FSA_HIP(counted_event_sync(mb.ev_pack[slot]));  // long done: no wait in steady state
         const int *mi = mb.mirror + slot * kMirrorInts;
         for (int d = 0; d < 2; d++) mb.size_out[d] = next_size(mi[d], g.record_cap);
@@ -180,9 +189,28 @@ static int incoming_sizes(Group &g, Member &mb, int size_in[2]) {
     return FSA_OK;
 }
 
+// Queues the pack of message `msg` for a member (with the integration of the step before when `with_advect`).
+static int pack_member(Group &g, Member &mb, long long msg, bool with_advect) {
+    Solver *s = mb.s;
+    int rc = outgoing_sizes(g, mb, msg);
+    if (rc) return rc;
+    const int slot = (int)(msg % kRing);
+    rc = launch_slab_pack_hash(s, with_advect, mb.own, mb.held, mb.left, mb.right, mb.send[0], mb.size_out[0],
+                               mb.send[1], mb.size_out[1], mb.mirror + slot * kMirrorInts);
+    if (rc) return rc;
+    FSA_HIP(hipEventRecord(mb.ev_pack[slot], s->stream));
+    // positions moved (or not: then nothing changes that was valid); hash / slot / cellCount describe the slots
+    if (with_advect) s->sorted_valid = s->lists_valid = s->hits_valid = false;
+    s->hash_valid = s->perm_valid = false;
+    s->hash_ahead = true;
+    s->count_stale = true;
+    mb.packed = true;
+    return FSA_OK;
+}
+
+// scan -> scatter -> rank + reorder -> density -> force of a member whose hash is ahead
 static int local_step(Solver *s) {
-    int rc = launch_hash_count(s);
-    if (!rc) rc = launch_sort_fused(s, false);
+    int rc = launch_sort_fused(s, false);
     if (rc) return rc;
     s->cur = 1 - s->cur;
     s->hash_valid = s->hash_ahead = false;
@@ -191,27 +219,19 @@ static int local_step(Solver *s) {
     s->perm_valid = s->index_table_valid = s->ref_cells_valid = false;
     rc = launch_density(s);
     if (!rc) rc = launch_force(s);
-    if (!rc) rc = launch_advect(s);
-    s->sorted_valid = false;  // positions moved
     return rc;
 }
 
 static int group_step(Group &g) {
-    const int slot = (int)(g.step % kRing), prev = (int)((g.step + kRing - 1) % kRing);
-    // ---- pack -------------------------------------------------------------------------------------------------
+    const long long msg = g.step;
+    const int slot = (int)(msg % kRing), prev = (int)((msg + kRing - 1) % kRing);
+    // ---- pack, where the step before has not left it done -----------------------------------------------------
     for (Member &mb : g.m) {
         Solver *s = mb.s;
         FSA_HIP(hipSetDevice(s->device));
-        int rc = outgoing_sizes(g, mb);
+        if (mb.packed && s->hash_ahead) continue;
+        int rc = pack_member(g, mb, msg, false);
         if (rc) return rc;
-        rc = launch_slab_pack_dev(s, mb.own, mb.held, mb.left, mb.right, mb.send[0], mb.size_out[0], mb.send[1],
-                                  mb.size_out[1], mb.mirror + slot * kMirrorInts);
-        if (rc) return rc;
-        FSA_HIP(hipEventRecord(mb.ev_pack[slot], s->stream));
-        s->cur = 1 - s->cur;  // the particles that stay went to the other copy
-        s->hash_valid = s->hash_ahead = s->perm_valid = s->sorted_valid = s->count_valid = false;
-        s->owned_from_sort = false;
-        s->count_stale = true;
     }
     // ---- transport ----------------------------------------------------------------------------------------------
     int size_in[2] = {0, 0};
@@ -224,7 +244,7 @@ static int group_step(Group &g) {
                 if (!mb.send[d]) continue;
                 Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
                 // the neighbour must be through with what it received in the step before
-                if (g.step > 0) FSA_HIP(hipStreamWaitEvent(s->stream, peer.ev_unpack[prev], 0));
+                if (msg > 0) FSA_HIP(hipStreamWaitEvent(s->stream, peer.ev_unpack[prev], 0));
                 const size_t bytes = (size_t)(1 + mb.size_out[d]) * g.rb;
                 char *dst = peer.recv[1 - d];
                 if (peer.s->device == s->device)
@@ -249,25 +269,30 @@ static int group_step(Group &g) {
         }
         FSA_NCCL(ncclGroupEnd());
     }
-    // ---- unpack and the solver's own step ---------------------------------------------------------------------
-    for (Member &mb : g.m) {
-        Solver *s = mb.s;
-        FSA_HIP(hipSetDevice(s->device));
-        int bound[2] = {0, 0};
+    // the bounds of what each member receives, before the next pack overwrites size_out
+    std::vector<int> bounds(2 * g.m.size(), 0);
+    for (size_t k = 0; k < g.m.size(); k++) {
+        Member &mb = g.m[k];
         for (int d = 0; d < 2; d++) {
             if (!mb.recv[d]) continue;
-            if (g.kind == 0) {
-                Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
-                FSA_HIP(hipStreamWaitEvent(s->stream, peer.ev_sent[1 - d], 0));
-                bound[d] = peer.size_out[1 - d];
-            } else {
-                bound[d] = size_in[d];
-            }
+            bounds[2 * k + d] = g.kind == 0 ? g.m[mb.rank + (d == 0 ? -1 : 1)].size_out[1 - d] : size_in[d];
         }
-        int rc = launch_slab_unpack_dev(s, mb.recv[0], bound[0], mb.recv[1], bound[1], mb.mirror + slot * kMirrorInts);
+    }
+    // ---- unpack, the solver's own step, and the pack of the next message ----------------------------------------
+    for (size_t k = 0; k < g.m.size(); k++) {
+        Member &mb = g.m[k];
+        Solver *s = mb.s;
+        FSA_HIP(hipSetDevice(s->device));
+        if (g.kind == 0)
+            for (int d = 0; d < 2; d++)
+                if (mb.recv[d]) FSA_HIP(hipStreamWaitEvent(s->stream, g.m[mb.rank + (d == 0 ? -1 : 1)].ev_sent[1 - d], 0));
+        int rc = launch_slab_unpack_hash(s, mb.recv[0], bounds[2 * k], mb.recv[1], bounds[2 * k + 1],
+                                         mb.mirror + slot * kMirrorInts);
         if (rc) return rc;
         FSA_HIP(hipEventRecord(mb.ev_unpack[slot], s->stream));
         rc = local_step(s);
+        if (rc) return rc;
+        rc = pack_member(g, mb, msg + 1, true);
         if (rc) return rc;
     }
     g.step++;

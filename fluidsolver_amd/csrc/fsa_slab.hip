@@ -15,6 +15,12 @@
 //   slab_unpack  records received from a neighbour are appended.
 //   rank_key     stable rank inside each cell by order key (replaces the by-source-index rank).
 //   slab_keys    new keys after the reorder.
+//
+// Slab groups (fsa_group.hip) run the same exchange without moving the particles that stay: one pass integrates,
+// classifies, writes the records and computes the next step's hash (dropped slots are marked, not compacted away),
+// a second appends the received records with their hash, and the sort that follows gathers what is left.
+#include "fsa_advect.h"
+#include "fsa_hash.h"
 #include "fsa_solver.h"
 
 namespace fsa {
@@ -281,20 +287,17 @@ __global__ __launch_bounds__(kBlock) void slab_init_keys_kernel(int n, const int
 // ---- exchange without host round trips (slab groups, fsa_group.hip) --------------------------------------------
 // (slabVars[]: fsa_solver.h)
 
-// After slab_pack_kernel: the counts leave the atomic counters (which go back to zero for the next pack), the
-// particle count becomes what stayed, each send buffer gets its count into its header slot, and a copy goes to
-// `mirror` (pinned host memory) for the host to read some steps later.  Counts beyond what the buffers take are
-// cut and flagged in slabVars[kVarError]: bit 0 capacity, 1 / 2 send buffer left / right.
-__global__ void slab_after_pack_kernel(int *__restrict__ counters, int *__restrict__ vars, int capKeep, int sizeLeft,
+// After slab_advect_pack_hash_kernel: the counts leave the atomic counters (which go back to zero for the next
+// pack), each send buffer gets its count into its header slot, and a copy goes to `mirror` (pinned host memory) for
+// the host to read some steps later.  Counts beyond what the messages take are cut and flagged in
+// slabVars[kVarError]: bits 1 / 2 send buffer left / right.  The particle count stays: nothing has been moved.
+__global__ void slab_after_pack_kernel(int *__restrict__ counters, int *__restrict__ vars, int sizeLeft,
                                        int sizeRight, long long *__restrict__ hdrLeft,
                                        long long *__restrict__ hdrRight, int *__restrict__ mirror) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int kept = counters[0], l = counters[1], r = counters[2], err = 0;
-    if (kept > capKeep) { kept = capKeep; err |= 1; }
+    int l = counters[1], r = counters[2], err = 0;
     if (l > sizeLeft) { l = sizeLeft; err |= 2; }
     if (r > sizeRight) { r = sizeRight; err |= 4; }
-    vars[kVarN] = kept;
-    vars[kVarKept] = kept;
     vars[kVarOutLeft] = l;
     vars[kVarOutRight] = r;
     vars[kVarLost] += counters[3];
@@ -304,7 +307,7 @@ __global__ void slab_after_pack_kernel(int *__restrict__ counters, int *__restri
     if (mirror) {
         mirror[0] = l;
         mirror[1] = r;
-        mirror[2] = kept;
+        mirror[2] = vars[kVarN];
         mirror[3] = vars[kVarError];
     }
     counters[0] = counters[1] = counters[2] = counters[3] = 0;
@@ -327,44 +330,169 @@ __device__ __forceinline__ void incoming_counts(const long long *hdrLeft, const 
     cr = (int)r;
 }
 
-// Appends the records of both receive buffers (left neighbour's first) behind the particles that stayed.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void slab_unpack_dev_kernel(const char *__restrict__ recvLeft,
-                                                                 const char *__restrict__ recvRight, int boundLeft,
-                                                                 int boundRight, const int *__restrict__ vars,
-                                                                 int capacity, Vec4<T> *__restrict__ posType,
-                                                                 Vec4<T> *__restrict__ velMass,
-                                                                 T *__restrict__ restDensity,
-                                                                 int *__restrict__ uniqueId,
-                                                                 long long *__restrict__ key) {
+// The integration, the classification of slab_pack_kernel and the cell hash of the next step in one pass over the
+// slots of the current arrays; nothing moves.  A particle this solver owned at the last sort is integrated (ADVECT;
+// AdvectKernel as in fsa_advect.h) and, by the layer it is in now, stays (its hash and arrival slot are computed,
+// its cell counted), goes out as a record to one or both neighbours, or both.  Every other slot -- halo copies of
+// the last step, particles that left the layers held here -- gets hash kHashDrop, which the sort skips.
+// cellCount must be all zero on entry.
+template <bool ADVECT>
+__global__ __launch_bounds__(kBlock) void slab_advect_pack_hash_kernel(
+    DevParams<float> P, int bound, int all_owned, SlabRanges R, const int *__restrict__ sortedHash,
+    float4 *__restrict__ posType, float4 *__restrict__ velMass, const Vec3<float> *__restrict__ force,
+    Vec3<float> *__restrict__ v_star, const float *__restrict__ restDensity, const int *__restrict__ uniqueId,
+    const long long *__restrict__ key, SlabRecord<float> *__restrict__ sendLeft, int capLeft,
+    SlabRecord<float> *__restrict__ sendRight, int capRight, int *__restrict__ counters, int *__restrict__ hash,
+    int *__restrict__ slot, int *__restrict__ cellCount, int *__restrict__ undefBlockCount) {
+    constexpr int kWaves = kBlock / 64;
+    __shared__ int waveCount[kWaves];
+    __shared__ int part[2][kWaves];  // left, right: particles flagged by each wave, then their prefix
+    __shared__ int base[2];
+    const int n = live_count(P, bound);
+    if ((int)blockIdx.x * kBlock >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p;
+    unsigned flags = 0;  // bit 0 keep, 1 left, 2 right
+    int lost = 0;
+    if (valid) {
+        bool owned = all_owned != 0;
+        if (!owned) {
+            const unsigned h = (unsigned)sortedHash[i];
+            if (h == FSA_GRID_UNDEF) {
+                owned = true;  // halo copies are always inside the grid when they arrive
+            } else {
+                const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
+                owned = gz >= R.own_lo && gz < R.own_hi;
+            }
+        }
+        if (owned) {
+            p = posType[i];
+            v = velMass[i];
+            if (ADVECT && advect_moves(P, unpack_int(p.w))) {
+                Vec3<float> vs;
+                advect_particle(P, p, v, force[i], vs);
+                v_star[i] = vs;
+                posType[i] = p;
+                velMass[i] = v;
+            }
+            bool inside = in_domain(P, p.x, p.y, p.z);
+            int cx = 0, cy = 0, cz = 0;
+            if (inside) {
+                calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
+                inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
+            }
+            if (!inside) {
+                flags = 1;  // out-of-grid particles stay with their owner
+            } else {
+                if (cz >= R.keep_lo && cz < R.keep_hi) flags |= 1;
+                if (cz >= R.left_lo && cz < R.left_hi) flags |= 2;
+                if (cz >= R.right_lo && cz < R.right_hi) flags |= 4;
+                if (flags == 0) lost = 1;
+            }
+        }
+    }
+    int before[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const unsigned long long m = __ballot((flags >> (c + 1)) & 1u);
+        before[c] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) part[c][wave] = __popcll(m);
+    }
+    if (lost) atomicAdd(counters + 3, 1);
+    const bool keep = (flags & 1u) != 0;
+    hash_and_count(P, keep, i, p.x, p.y, p.z, hash, slot, cellCount, undefBlockCount, waveCount);  // has a barrier
+    if (valid && !keep) hash[i] = (int)kHashDrop;
+    if (threadIdx.x < 2) {  // exclusive prefix over the waves and one atomic for a block that sends anything
+        const int c = threadIdx.x;
+        int run = 0;
+        for (int w = 0; w < kWaves; w++) {
+            const int t = part[c][w];
+            part[c][w] = run;
+            run += t;
+        }
+        base[c] = run ? atomicAdd(counters + 1 + c, run) : 0;
+    }
+    __syncthreads();
+    if (flags & 6u) {
+        SlabRecord<float> rec{};
+        rec.posType = p;
+        rec.velMass = v;
+        rec.orderKey = key[i];
+        rec.restDensity = restDensity[i];
+        rec.uniqueId = uniqueId[i];
+        if (flags & 2u) {
+            const int at = base[0] + part[0][wave] + before[0];
+            if (at < capLeft) sendLeft[at] = rec;
+        }
+        if (flags & 4u) {
+            const int at = base[1] + part[1][wave] + before[1];
+            if (at < capRight) sendRight[at] = rec;
+        }
+    }
+}
+
+// Appends the records of both receive buffers (left neighbour's first) behind the slots the arrays hold, with
+// their hash and arrival slots (they lie in the layers this solver holds: the sender selected them by that).
+__global__ __launch_bounds__(kBlock) void slab_unpack_hash_kernel(
+    DevParams<float> P, const char *__restrict__ recvLeft, const char *__restrict__ recvRight, int boundLeft,
+    int boundRight, const int *__restrict__ vars, int capacity, float4 *__restrict__ posType,
+    float4 *__restrict__ velMass, float *__restrict__ restDensity, int *__restrict__ uniqueId,
+    long long *__restrict__ key, int *__restrict__ hash, int *__restrict__ slot, int *__restrict__ cellCount,
+    int *__restrict__ undefBlockCount, int *__restrict__ counters) {
     const int at = vars[kVarN];
     int cl, cr, err;
     incoming_counts((const long long *)recvLeft, (const long long *)recvRight, boundLeft, boundRight, at, capacity, cl,
                     cr, err);
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= cl + cr) return;
-    const SlabRecord<T> *src = k < cl ? (const SlabRecord<T> *)(recvLeft + sizeof(SlabRecord<T>)) + k
-                                      : (const SlabRecord<T> *)(recvRight + sizeof(SlabRecord<T>)) + (k - cl);
-    const SlabRecord<T> r = *src;
-    posType[at + k] = r.posType;
-    velMass[at + k] = r.velMass;
-    restDensity[at + k] = r.restDensity;
-    uniqueId[at + k] = r.uniqueId;
-    key[at + k] = r.orderKey;
+    if ((int)blockIdx.x * kBlock >= cl + cr) return;
+    const bool valid = k < cl + cr;
+    const int i = at + k;
+    unsigned h = kHashDrop;
+    if (valid) {
+        const SlabRecord<float> *src = k < cl ? (const SlabRecord<float> *)(recvLeft + sizeof(SlabRecord<float>)) + k
+                                              : (const SlabRecord<float> *)(recvRight + sizeof(SlabRecord<float>)) + (k - cl);
+        const SlabRecord<float> r = *src;
+        posType[i] = r.posType;
+        velMass[i] = r.velMass;
+        restDensity[i] = r.restDensity;
+        uniqueId[i] = r.uniqueId;
+        key[i] = r.orderKey;
+        if (in_domain(P, r.posType.x, r.posType.y, r.posType.z)) {
+            int cx, cy, cz;
+            calc_grid_pos(P, r.posType.x, r.posType.y, r.posType.z, cx, cy, cz);
+            h = calc_grid_hash(P, cx, cy, cz);
+        }
+        if (h == FSA_GRID_UNDEF || h == kHashDrop) {  // not in the layers held here: nobody should have sent it
+            h = kHashDrop;
+            atomicAdd(counters + 3, 1);
+        }
+        // out-of-grid ranks are kept per block of kBlock slots; the blocks that begin in the appended part have none
+        if (i % kBlock == 0) undefBlockCount[i / kBlock] = 0;
+    }
+    const int my = count_in_cell(valid && h != kHashDrop, h, cellCount);
+    if (valid) {
+        hash[i] = (int)h;
+        slot[i] = my;
+    }
 }
 
+// The number of slots after the append (what the sort reads), the counts, and their mirror for the host.
 __global__ void slab_after_unpack_kernel(const char *__restrict__ recvLeft, const char *__restrict__ recvRight,
                                          int boundLeft, int boundRight, int *__restrict__ vars, int capacity,
-                                         int *__restrict__ mirror) {
+                                         int *__restrict__ counters, int *__restrict__ mirror) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int at = vars[kVarN];
     int cl, cr, err;
     incoming_counts((const long long *)recvLeft, (const long long *)recvRight, boundLeft, boundRight, at, capacity, cl,
                     cr, err);
-    vars[kVarN] = at + cl + cr;
+    vars[kVarSlots] = at + cl + cr;
     vars[kVarInLeft] = cl;
     vars[kVarInRight] = cr;
     vars[kVarError] |= err;
+    vars[kVarLost] += counters[3];
+    counters[3] = 0;
     if (mirror) {
         mirror[4] = cl;
         mirror[5] = cr;
@@ -477,42 +605,52 @@ int launch_slab_unpack(Solver *s, const void *recs, int count) {
     return FSA_OK;
 }
 
-// Pack for a group step: no counts come back to the host.  sendLeft / sendRight are whole send buffers (header slot
-// first); sizeLeft / sizeRight the records this step's messages take.
-int launch_slab_pack_dev(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
-                         void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror) {
-    const int rb = slab_record_bytes(s);
-    ScopedTimer t(s, "slab_pack");
+// The exchange of a group step, sending side (no counts come back to the host).  sendLeft / sendRight are whole
+// send buffers (header slot first); sizeLeft / sizeRight the records this step's messages take.  with_advect: the
+// integration of the step before runs in the same pass.
+int launch_slab_pack_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
+                          const int right[2], void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror) {
+    const int rb = slab_record_bytes(s), c = s->cur, n = s->grid_n();
+    if (!s->counts_clean) {
+        ScopedTimer t(s, "clear_counts");
+        FSA_HIP(hipMemsetAsync(s->b.cellCount, 0, (size_t)s->num_cells * sizeof(int), s->stream));
+    }
+    s->counts_clean = false;
+    ScopedTimer t(s, with_advect ? "advect_pack_hash" : "pack_hash");
     SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1]};
     char *l = (char *)sendLeft, *r = (char *)sendRight;
-    int rc = s->precision == FSA_PRECISION_F32
-                 ? pack_t<float>(s, s->pf, R, l ? l + rb : nullptr, l ? sizeLeft : 0, r ? r + rb : nullptr, r ? sizeRight : 0)
-                 : pack_t<double>(s, s->pd, R, l ? l + rb : nullptr, l ? sizeLeft : 0, r ? r + rb : nullptr, r ? sizeRight : 0);
-    if (rc) return rc;
+#define FSA_APH(ADV)                                                                                                  \
+    hipLaunchKernelGGL(slab_advect_pack_hash_kernel<ADV>, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->pf, n,  \
+                       s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (float4 *)s->b.posType[c],                     \
+                       (float4 *)s->b.velMass[c], (const Vec3<float> *)s->b.force, (Vec3<float> *)s->b.v_star,        \
+                       (const float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c],                        \
+                       (SlabRecord<float> *)(l ? l + rb : nullptr), l ? sizeLeft : 0,                                 \
+                       (SlabRecord<float> *)(r ? r + rb : nullptr), r ? sizeRight : 0, s->b.slabCounters, s->b.hash,  \
+                       s->b.slot, s->b.cellCount, s->b.undefBlockCount)
+    if (n > 0) {
+        if (with_advect) FSA_APH(true); else FSA_APH(false);
+    }
+#undef FSA_APH
     hipLaunchKernelGGL(slab_after_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->b.slabCounters, s->b.slabVars,
-                       s->capacity, l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
+                       l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
 
-int launch_slab_unpack_dev(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
-                           int *mirror) {
-    ScopedTimer t(s, "slab_unpack");
+// Receiving side: append, hash, and the slot count for the sort.
+int launch_slab_unpack_hash(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
+                            int *mirror) {
+    ScopedTimer t(s, "unpack_hash");
     const int c = s->cur, bound = (recvLeft ? boundLeft : 0) + (recvRight ? boundRight : 0);
-    if (bound > 0) {
-        if (s->precision == FSA_PRECISION_F32)
-            hipLaunchKernelGGL(slab_unpack_dev_kernel<float>, dim3(blocks_for(bound)), dim3(kBlock), 0, s->stream,
-                               (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
-                               s->capacity, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
-                               (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c]);
-        else
-            hipLaunchKernelGGL(slab_unpack_dev_kernel<double>, dim3(blocks_for(bound)), dim3(kBlock), 0, s->stream,
-                               (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
-                               s->capacity, (double4 *)s->b.posType[c], (double4 *)s->b.velMass[c],
-                               (double *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c]);
-    }
+    if (bound > 0)
+        hipLaunchKernelGGL(slab_unpack_hash_kernel, dim3(blocks_for(bound)), dim3(kBlock), 0, s->stream, s->pf,
+                           (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
+                           s->capacity, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
+                           (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c], s->b.hash, s->b.slot,
+                           s->b.cellCount, s->b.undefBlockCount, s->b.slabCounters);
     hipLaunchKernelGGL(slab_after_unpack_kernel, dim3(1), dim3(64), 0, s->stream, (const char *)recvLeft,
-                       (const char *)recvRight, boundLeft, boundRight, s->b.slabVars, s->capacity, mirror);
+                       (const char *)recvRight, boundLeft, boundRight, s->b.slabVars, s->capacity, s->b.slabCounters,
+                       mirror);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

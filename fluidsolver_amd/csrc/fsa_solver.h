@@ -120,6 +120,8 @@ struct Solver {
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
+    const int *slab_slots = nullptr;  // member of a slab group: number of slots the arrays hold before the sort (the
+                                      // sort drops the particles that left; device memory, slabVars[kVarSlots])
     int variant = 3;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32,
                       // 3 as 2 with one neighbour search per step (fsa_sph_fast.hip; same bits as 2)
     // number of particles the launch grids must cover: n, or the capacity while n lives on the device
@@ -140,7 +142,7 @@ struct Solver {
 };
 
 // slabVars[] of a z-slab solver in a group (device memory): the particle count and the counts of the last exchange
-enum { kVarN = 0, kVarKept, kVarOutLeft, kVarOutRight, kVarLost, kVarError, kVarInLeft, kVarInRight, kVarCount };
+enum { kVarN = 0, kVarKept, kVarOutLeft, kVarOutRight, kVarLost, kVarError, kVarInLeft, kVarInRight, kVarSlots, kVarCount };
 
 // Every place where the library makes the host wait for the device goes through these, which count the waits
 // (fsa_debug_host_waits: tests assert that a slab group step makes none).
@@ -219,10 +221,10 @@ int launch_slab_keys(Solver *s);
 int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
                      void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
 int launch_slab_unpack(Solver *s, const void *recs, int count);
-int launch_slab_pack_dev(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
-                         void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror);
-int launch_slab_unpack_dev(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
-                           int *mirror);
+int launch_slab_pack_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
+                          const int right[2], void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror);
+int launch_slab_unpack_hash(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
+                            int *mirror);
 int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *count);
 int launch_pack(Solver *s, int n, const void *d_pos3, const void *d_vel3, const int *d_type, const void *d_mass);
 int launch_unpack_vec3(Solver *s, const void *src4, void *dst3, int n);

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                 group_d2<true>(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], pi.x, pi.y, pi.z, d2);
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    if (EVAL) q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
+                    if (EVAL && !(dbg & 16)) q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
                     if constexpr (!MASKED && EVAL) {
                         // one compare, then the hit goes into the queue count and into the bit mask as a carry
                         unsigned long long carry_out;
@@ -642,7 +642,7 @@ static inline int tiled_grid(const Solver *s, int run_log) {
 template <bool EVAL> static int launch_density_record(Solver *s) {
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
     FSA_HIP(hipMemsetAsync(s->b.wallList, 0, sizeof(int), s->stream));  // the list of the wall pass starts empty
-    hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, run_log)),
+    hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, s->xcd_run_log)),
                        dim3(kTunedBS), 0, s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c],
                        (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
                        s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, s->b.wallCount, s->b.wallList,
@@ -678,7 +678,7 @@ int launch_force_fast(Solver *s) {
                            (const uint2 *)s->b.hitWords, s->b.wallCount, (float4 *)s->b.wallForce);
     }
     ScopedTimer t(s, "force");
-    hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, run_log)), dim3(kTunedBS), 0,
+    hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, s->xcd_run_log)), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                        (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
                        s->b.hitCount, s->b.wallCount, (const float4 *)s->b.wallForce, (Vec3<float> *)s->b.force, run_log);

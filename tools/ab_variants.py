@@ -14,6 +14,7 @@ a = ap.parse_args()
 sc = bench.build_scene(a.scene, a.jitter)
 p = capi.make_params(0, **sc["params"])
 s = capi.Solver(p, len(sc["pos"])); s.upload(sc)
+s.set_variant(2)  # the experiment flags of variant 3 (FSA_FAST_DBG) must not disturb the spin-up
 s.step(a.spinup); s.sort_particles(); s.synchronize()
 ref = None
 out = {}
