@@ -103,6 +103,7 @@ template <typename T> static void to_dev_params(const fsa_params &h, DevParams<T
     d.num_cells = h.gridres[0] * h.gridres[1] * d.nz;
     d.own_lo = -(1 << 30);
     d.own_hi = 1 << 30;
+    d.edge[0] = d.edge[1] = d.edge[2] = d.edge[3] = 0;
     d.rows = nullptr;
     d.big = nullptr;
     d.count = nullptr;
@@ -401,6 +402,7 @@ int fsa_copy_param_to_device(fsa_solver *hs, const fsa_params *p) {
     if (nf.num_cells != s->num_cells || nf.gres[0] != s->pf.gres[0] || nf.gres[1] != s->pf.gres[1] ||
         nf.gres[2] != s->pf.gres[2] || nf.z0 != s->pf.z0 || nf.nz != s->pf.nz)
         return fail(FSA_ERR_INVALID, "grid resolution / slab differ from the ones the solver was created with");
+    if (s->pf.count) return fail(FSA_ERR_INVALID, "the solver is a member of a slab group: destroy the group first");
     const int own_lo = s->pf.own_lo, own_hi = s->pf.own_hi;
     s->hp = *p;
     to_dev_params(*p, s->pf);

@@ -59,6 +59,10 @@ template <typename T> struct DevParams {
     // z-slab runs: global layers [own_lo, own_hi) whose particles need forces (density: one layer more on
     // each side); what else the solver holds is halo, whose results nobody reads.  Default: everything.
     int own_lo, own_hi;
+    // z-slab groups: the global layers next to the cuts, [edge[0], edge[1]) on the left and [edge[2], edge[3]) on
+    // the right (empty where there is no neighbour): a particle that may have to go out to a neighbour after the
+    // integration was in one of them at the last sort.  Their forces are computed and their records sent first.
+    int edge[4];
     // fp32 solvers: the row table of the tiled passes for the current sorted order (see fsa_tile.h), else null
     const int *rows;
     const int *big;   // [0] = number of blocks with large tiles, then their ids (fsa_tile.h); rebuilt with `rows`
@@ -132,6 +136,28 @@ __device__ __forceinline__ bool run_unneeded(const DevParams<T> &P, unsigned hlo
     if (ylo == yhi) return lhi < need_lo || llo >= need_hi;
     if (yhi == ylo + 1) return llo >= need_hi && lhi < need_lo;
     return false;
+}
+
+template <typename T> __device__ __forceinline__ bool layer_in_edge(const DevParams<T> &P, int gz) {
+    return (gz >= P.edge[0] && gz < P.edge[1]) || (gz >= P.edge[2] && gz < P.edge[3]);
+}
+// Does a run of consecutive sorted particles from cell hlo to cell hhi (both in the grid) hold a layer of an edge?
+template <typename T> __device__ __forceinline__ bool run_touches_edge(const DevParams<T> &P, unsigned hlo, unsigned hhi) {
+    const unsigned gx = (unsigned)P.gres[0], nz = (unsigned)P.nz;
+    const int ylo = (int)(hlo / (gx * nz)), yhi = (int)(hhi / (gx * nz));
+    const int llo = (int)((hlo / gx) % nz), lhi = (int)((hhi / gx) % nz);
+    if (yhi > ylo + 1) return P.edge[0] < P.edge[1] || P.edge[2] < P.edge[3];
+    bool touch = false;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const int lo = P.edge[e] - P.z0, hi = P.edge[e + 1] - P.z0;  // local layers
+        if (lo >= hi) continue;
+        if (ylo == yhi)
+            touch |= lhi >= lo && llo < hi;
+        else
+            touch |= llo < hi || lhi >= lo;  // the tail of one y and the head of the next
+    }
+    return touch;
 }
 
 // Kernel_Cubic, solver/sph_kernel_impl.cuh:32-40, from the squared norm d2 = x*x + y*y + z*z

@@ -7,18 +7,23 @@
 // lives in device memory (DevParams::count), the pack and unpack kernels keep it and the message counts up to
 // date there, and launch grids are sized for the solver's capacity.
 //
-//   pack       one pass over the particles does the integration of the step before, decides by the new position who
-//              stays, who goes out as a record to the left or right neighbour and who is dropped (the halo copies of
-//              the step before), and computes the hash and cell counts of those that stay (fsa_slab.hip); nothing is
-//              moved, the sort gathers what is left.  A one-thread kernel turns the atomic counters into the message
-//              headers.  The pack of step k + 1 thus runs at the end of step k;
+//   pack       two passes (fsa_slab.hip).  The first integrates the particles of the layers next to the cuts and
+//              writes those that are now in a neighbour's layers as records; a one-thread kernel turns the atomic
+//              counters into the message headers.  The second integrates the rest, decides who stays and who is
+//              dropped (the halo copies of the step before) and computes the hash and cell counts of those that
+//              stay; nothing is moved, the sort gathers what is left.  The pack of step k + 1 thus runs at the end
+//              of step k, and so does its transport, on a stream of its own: the force pass handles the blocks next
+//              to the cuts first, then come the first pack pass and the transport, and the force pass of all other
+//              blocks and the second pack pass run while the records travel;
 //   transport  LOCAL: all slabs belong to solvers of this process (on one GPU or several): the send buffer is
 //              copied into the neighbour's receive buffer on the sender's stream, events order it against the
 //              neighbour's unpack of this step and of the step before;
 //              RCCL: one slab per process: ncclSend / ncclRecv to both z-neighbours in one group call on the
 //              solver's stream (xGMI between the GPUs of a node);
-//   unpack     records of both receive buffers are appended and hashed, the number of slots is raised;
+//   unpack     (start of the next step, once the transport is through) records of both receive buffers are appended
+//              and hashed, the number of slots is raised;
 //   then scan -> scatter -> rank + reorder (the particle count becomes what the sort kept) -> density -> force.
+// FSA_SLAB_OVERLAP=0 (read when a group is made) keeps everything on the solver's stream, for comparison.
 //
 // Message sizes.  A send or copy needs its size on the host when it is queued, and the host does not know this
 // step's counts.  Both ends therefore size the message of step k from the count of step k - kLag, which each of
@@ -30,6 +35,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -51,12 +57,16 @@ struct Member {
     char *recv[2] = {nullptr, nullptr};  // [0] from the left neighbour, [1] from the right
     int *mirror = nullptr;               // pinned host memory: kRing x kMirrorInts
     hipEvent_t ev_pack[kRing] = {}, ev_unpack[kRing] = {}, ev_sent[2] = {};
-    int size_out[2] = {0, 0};            // records the messages take that are packed (or were sent last)
-    bool packed = false;                 // the send buffers hold the next message (and the solver's hash is ahead)
+    hipEvent_t ev_arrived = nullptr;     // RCCL: this step's messages are in the receive buffers
+    hipStream_t comm = nullptr;          // the transport's stream (the solver's own without overlap)
+    int size_out[2] = {0, 0};            // records the messages take that were packed last
+    int bound_in[2] = {0, 0};            // records the messages can hold that are on their way here
+    bool ahead = false;                  // the next step's messages are packed and on their way, the hash is ahead
 };
 
 struct Group {
     int kind = 0;  // 0 LOCAL, 1 RCCL
+    bool overlap = true;
     int world = 0, halo = 0, record_cap = 0, rb = 0;
     std::vector<int> cuts;
     std::vector<Member> m;
@@ -64,6 +74,11 @@ struct Group {
     long long step = 0;  // steps queued since the group was made
     long long sent = 0;  // records sent by this process's members, as far as the host has seen the counts
 };
+
+static bool overlap_wanted() {
+    const char *e = getenv("FSA_SLAB_OVERLAP");
+    return !(e && e[0] == '0');
+}
 
 static int next_size(int count, int cap) {
     const long long v = (long long)count + count / 8 + 4096;
@@ -98,6 +113,8 @@ static void free_member(Member &mb) {
             if (hipMemcpy(&n, mb.s->b.slabVars + kVarN, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) mb.s->n = n;
             mb.s->pf.count = mb.s->pd.count = nullptr;
             mb.s->slab_slots = nullptr;
+            mb.s->force_zone = 0;
+            for (int e = 0; e < 4; e++) mb.s->pf.edge[e] = mb.s->pd.edge[e] = 0;
             mb.s->count_stale = false;
             // hash[] may hold the marks of a pack whose message never went out
             mb.s->hash_valid = mb.s->hash_ahead = false;
@@ -111,6 +128,11 @@ static void free_member(Member &mb) {
     for (int k = 0; k < kRing; k++) {
         if (mb.ev_pack[k]) (void)hipEventDestroy(mb.ev_pack[k]);
         if (mb.ev_unpack[k]) (void)hipEventDestroy(mb.ev_unpack[k]);
+    }
+    if (mb.ev_arrived) (void)hipEventDestroy(mb.ev_arrived);
+    if (mb.comm && mb.s && mb.comm != mb.s->stream) {
+        (void)hipStreamSynchronize(mb.comm);
+        (void)hipStreamDestroy(mb.comm);
     }
     if (mb.mirror) (void)hipHostFree(mb.mirror);
 }
@@ -147,6 +169,9 @@ static int setup_member(Group &g, Member &mb, Solver *s, int rank) {
         FSA_HIP(hipEventCreateWithFlags(&mb.ev_pack[k], hipEventDisableTiming));
         FSA_HIP(hipEventCreateWithFlags(&mb.ev_unpack[k], hipEventDisableTiming));
     }
+    FSA_HIP(hipEventCreateWithFlags(&mb.ev_arrived, hipEventDisableTiming));
+    mb.comm = s->stream;
+    if (g.overlap) FSA_HIP(hipStreamCreateWithFlags(&mb.comm, hipStreamNonBlocking));
     FSA_HIP(hipHostMalloc((void **)&mb.mirror, sizeof(int) * kRing * kMirrorInts, hipHostMallocDefault));
     std::memset(mb.mirror, 0, sizeof(int) * kRing * kMirrorInts);
     // from here on the count lives on the device
@@ -161,6 +186,13 @@ static int setup_member(Group &g, Member &mb, Solver *s, int rank) {
     s->hash_valid = s->hash_ahead = false;
     s->pf.own_lo = s->pd.own_lo = mb.own[0];
     s->pf.own_hi = s->pd.own_hi = mb.own[1];
+    // the layers a particle can leave for a neighbour from in one step (it would have to cross more than two to
+    // get there from anywhere else; the pack flags that)
+    const int reach = g.halo + 2;
+    int edge[4] = {0, 0, 0, 0};
+    if (mb.has_left) { edge[0] = mb.own[0]; edge[1] = std::min(mb.own[0] + reach, mb.own[1]); }
+    if (mb.has_right) { edge[2] = std::max(mb.own[1] - reach, mb.own[0]); edge[3] = mb.own[1]; }
+    for (int e = 0; e < 4; e++) s->pf.edge[e] = s->pd.edge[e] = edge[e];
     return FSA_OK;
 }
 
@@ -177,11 +209,11 @@ static int outgoing_sizes(Group &g, Member &mb, long long msg) {
     return FSA_OK;
 }
 
-// RCCL: the sizes of the two incoming messages, from the headers received kLag steps ago.
-static int incoming_sizes(Group &g, Member &mb, int size_in[2]) {
+// RCCL: the sizes of the two incoming messages of step `msg`, from the headers received kLag steps before.
+static int incoming_sizes(Group &g, Member &mb, long long msg, int size_in[2]) {
     size_in[0] = size_in[1] = g.record_cap;
-    if (g.step >= kLag) {
-        const int slot = (int)((g.step - kLag) % kRing);
+    if (msg >= kLag) {
+        const int slot = (int)((msg - kLag) % kRing);
         FSA_HIP(counted_event_sync(mb.ev_unpack[slot]));
         const int *mi = mb.mirror + slot * kMirrorInts;
         for (int d = 0; d < 2; d++) size_in[d] = next_size(mi[4 + d], g.record_cap);
@@ -189,110 +221,173 @@ static int incoming_sizes(Group &g, Member &mb, int size_in[2]) {
     return FSA_OK;
 }
 
-// Queues the pack of message `msg` for a member (with the integration of the step before when `with_advect`).
-static int pack_member(Group &g, Member &mb, long long msg, bool with_advect) {
+// First pack pass of message `msg` for a member (with the integration of the step before when `with_advect`).
+static int pack_edges(Group &g, Member &mb, long long msg, bool with_advect) {
     Solver *s = mb.s;
     int rc = outgoing_sizes(g, mb, msg);
     if (rc) return rc;
     const int slot = (int)(msg % kRing);
-    rc = launch_slab_pack_hash(s, with_advect, mb.own, mb.held, mb.left, mb.right, mb.send[0], mb.size_out[0],
-                               mb.send[1], mb.size_out[1], mb.mirror + slot * kMirrorInts);
+    rc = launch_slab_edge_send(s, with_advect, mb.own, mb.left, mb.right, mb.send[0], mb.size_out[0], mb.send[1],
+                               mb.size_out[1], mb.mirror + slot * kMirrorInts);
     if (rc) return rc;
     FSA_HIP(hipEventRecord(mb.ev_pack[slot], s->stream));
-    // positions moved (or not: then nothing changes that was valid); hash / slot / cellCount describe the slots
-    if (with_advect) s->sorted_valid = s->lists_valid = s->hits_valid = false;
-    s->hash_valid = s->perm_valid = false;
-    s->hash_ahead = true;
     s->count_stale = true;
-    mb.packed = true;
     return FSA_OK;
 }
 
-// scan -> scatter -> rank + reorder -> density -> force of a member whose hash is ahead
-static int local_step(Solver *s) {
-    int rc = launch_sort_fused(s, false);
-    if (rc) return rc;
-    s->cur = 1 - s->cur;
-    s->hash_valid = s->hash_ahead = false;
-    s->sorted_valid = s->owned_from_sort = s->count_valid = true;
-    s->pd_valid = s->lists_valid = s->hits_valid = false;
-    s->perm_valid = s->index_table_valid = s->ref_cells_valid = false;
-    rc = launch_density(s);
-    if (!rc) rc = launch_force(s);
-    return rc;
-}
-
-static int group_step(Group &g) {
-    const long long msg = g.step;
+// Transport of message `msg`, queued on the members' transport streams behind their first pack pass.
+static int transport(Group &g, long long msg) {
     const int slot = (int)(msg % kRing), prev = (int)((msg + kRing - 1) % kRing);
-    // ---- pack, where the step before has not left it done -----------------------------------------------------
-    for (Member &mb : g.m) {
-        Solver *s = mb.s;
-        FSA_HIP(hipSetDevice(s->device));
-        if (mb.packed && s->hash_ahead) continue;
-        int rc = pack_member(g, mb, msg, false);
-        if (rc) return rc;
-    }
-    // ---- transport ----------------------------------------------------------------------------------------------
-    int size_in[2] = {0, 0};
     if (g.kind == 0) {
         for (Member &mb : g.m) {
             Solver *s = mb.s;
             FSA_HIP(hipSetDevice(s->device));
-            ScopedTimer t(s, "exchange");
-            for (int d = 0; d < 2; d++) {
-                if (!mb.send[d]) continue;
-                Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
-                // the neighbour must be through with what it received in the step before
-                if (msg > 0) FSA_HIP(hipStreamWaitEvent(s->stream, peer.ev_unpack[prev], 0));
-                const size_t bytes = (size_t)(1 + mb.size_out[d]) * g.rb;
-                char *dst = peer.recv[1 - d];
-                if (peer.s->device == s->device)
-                    FSA_HIP(hipMemcpyAsync(dst, mb.send[d], bytes, hipMemcpyDeviceToDevice, s->stream));
-                else
-                    FSA_HIP(hipMemcpyPeerAsync(dst, peer.s->device, mb.send[d], s->device, bytes, s->stream));
-                FSA_HIP(hipEventRecord(mb.ev_sent[d], s->stream));
+            hipStream_t main = s->stream;
+            if (mb.comm != main) FSA_HIP(hipStreamWaitEvent(mb.comm, mb.ev_pack[slot], 0));
+            s->stream = mb.comm;  // (the timer brackets the stream the copies run on)
+            {
+                ScopedTimer t(s, "exchange");
+                for (int d = 0; d < 2; d++) {
+                    if (!mb.send[d]) continue;
+                    Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
+                    // the neighbour must be through with what it received in the step before
+                    if (msg > 0) (void)hipStreamWaitEvent(mb.comm, peer.ev_unpack[prev], 0);
+                    const size_t bytes = (size_t)(1 + mb.size_out[d]) * g.rb;
+                    char *dst = peer.recv[1 - d];
+                    if (peer.s->device == s->device)
+                        (void)hipMemcpyAsync(dst, mb.send[d], bytes, hipMemcpyDeviceToDevice, mb.comm);
+                    else
+                        (void)hipMemcpyPeerAsync(dst, peer.s->device, mb.send[d], s->device, bytes, mb.comm);
+                    (void)hipEventRecord(mb.ev_sent[d], mb.comm);
+                    peer.bound_in[1 - d] = mb.size_out[d];
+                }
             }
+            s->stream = main;
+            FSA_HIP(hipGetLastError());
         }
     } else {
         Member &mb = g.m[0];
         Solver *s = mb.s;
-        int rc = incoming_sizes(g, mb, size_in);
+        int size_in[2] = {0, 0};
+        int rc = incoming_sizes(g, mb, msg, size_in);
         if (rc) return rc;
-        ScopedTimer t(s, "exchange");
-        FSA_NCCL(ncclGroupStart());
-        for (int d = 0; d < 2; d++) {
-            if (!mb.send[d]) continue;
-            const int peer = mb.rank + (d == 0 ? -1 : 1);
-            FSA_NCCL(ncclSend(mb.send[d], (size_t)(1 + mb.size_out[d]) * g.rb, ncclChar, peer, g.comm, s->stream));
-            FSA_NCCL(ncclRecv(mb.recv[d], (size_t)(1 + size_in[d]) * g.rb, ncclChar, peer, g.comm, s->stream));
+        hipStream_t main = s->stream;
+        if (mb.comm != main) FSA_HIP(hipStreamWaitEvent(mb.comm, mb.ev_pack[slot], 0));
+        s->stream = mb.comm;
+        ncclResult_t nr = ncclSuccess;
+        {
+            ScopedTimer t(s, "exchange");
+            nr = ncclGroupStart();
+            for (int d = 0; d < 2 && nr == ncclSuccess; d++) {
+                if (!mb.send[d]) continue;
+                const int peer = mb.rank + (d == 0 ? -1 : 1);
+                nr = ncclSend(mb.send[d], (size_t)(1 + mb.size_out[d]) * g.rb, ncclChar, peer, g.comm, mb.comm);
+                if (nr == ncclSuccess)
+                    nr = ncclRecv(mb.recv[d], (size_t)(1 + size_in[d]) * g.rb, ncclChar, peer, g.comm, mb.comm);
+                mb.bound_in[d] = size_in[d];
+            }
+            const ncclResult_t ne = ncclGroupEnd();
+            if (nr == ncclSuccess) nr = ne;
         }
-        FSA_NCCL(ncclGroupEnd());
+        s->stream = main;
+        if (nr != ncclSuccess) return fail(FSA_ERR_HIP, "RCCL send / receive failed: %s", ncclGetErrorString(nr));
+        FSA_HIP(hipEventRecord(mb.ev_arrived, mb.comm));
     }
-    // the bounds of what each member receives, before the next pack overwrites size_out
-    std::vector<int> bounds(2 * g.m.size(), 0);
-    for (size_t k = 0; k < g.m.size(); k++) {
-        Member &mb = g.m[k];
-        for (int d = 0; d < 2; d++) {
-            if (!mb.recv[d]) continue;
-            bounds[2 * k + d] = g.kind == 0 ? g.m[mb.rank + (d == 0 ? -1 : 1)].size_out[1 - d] : size_in[d];
+    return FSA_OK;
+}
+
+// Second pack pass of a member.
+static int pack_rest(Member &mb, bool with_advect) {
+    Solver *s = mb.s;
+    int rc = launch_slab_keep_hash(s, with_advect, mb.own, mb.held, mb.left, mb.right);
+    if (rc) return rc;
+    if (with_advect) s->sorted_valid = s->lists_valid = s->hits_valid = false;  // positions moved
+    s->hash_valid = s->perm_valid = false;
+    s->hash_ahead = true;  // hash / slot / cellCount describe the slots of the current arrays
+    mb.ahead = true;
+    return FSA_OK;
+}
+
+static int group_step(Group &g) {
+    const long long msg = g.step;
+    const int slot = (int)(msg % kRing);
+    // ---- pack and transport of this step's messages, where the step before has not left them done --------------
+    bool any = false, all = true;
+    for (Member &mb : g.m) {
+        const bool ahead = mb.ahead && mb.s->hash_ahead;
+        any |= ahead;
+        all &= ahead;
+    }
+    if (any && !all)
+        return fail(FSA_ERR_INVALID, "the particles of a member of the slab group were changed between two steps of the "
+                                     "group: destroy the group and make a new one");
+    if (g.kind == 1 && msg > 0 && !all)
+        return fail(FSA_ERR_INVALID, "the particles of a member of the slab group were changed between two steps of the "
+                                     "group (its messages are already with the neighbours): destroy the group and make a "
+                                     "new one");
+    if (!all) {
+        for (Member &mb : g.m) {
+            FSA_HIP(hipSetDevice(mb.s->device));
+            int rc = pack_edges(g, mb, msg, false);
+            if (rc) return rc;
+        }
+        int rc = transport(g, msg);
+        if (rc) return rc;
+        for (Member &mb : g.m) {
+            FSA_HIP(hipSetDevice(mb.s->device));
+            rc = pack_rest(mb, false);
+            if (rc) return rc;
         }
     }
-    // ---- unpack, the solver's own step, and the pack of the next message ----------------------------------------
-    for (size_t k = 0; k < g.m.size(); k++) {
-        Member &mb = g.m[k];
+    // ---- unpack, the solver's own step up to the forces next to the cuts, first pack pass of the next message ----
+    for (Member &mb : g.m) {
         Solver *s = mb.s;
         FSA_HIP(hipSetDevice(s->device));
-        if (g.kind == 0)
-            for (int d = 0; d < 2; d++)
-                if (mb.recv[d]) FSA_HIP(hipStreamWaitEvent(s->stream, g.m[mb.rank + (d == 0 ? -1 : 1)].ev_sent[1 - d], 0));
-        int rc = launch_slab_unpack_hash(s, mb.recv[0], bounds[2 * k], mb.recv[1], bounds[2 * k + 1],
+        if (g.kind == 0) {
+            for (int d = 0; d < 2; d++) {
+                if (!mb.recv[d]) continue;
+                FSA_HIP(hipStreamWaitEvent(s->stream, g.m[mb.rank + (d == 0 ? -1 : 1)].ev_sent[1 - d], 0));
+                // and this member's own copies have left its send buffers, which the next pack overwrites
+                if (mb.comm != s->stream) FSA_HIP(hipStreamWaitEvent(s->stream, mb.ev_sent[d], 0));
+            }
+        } else if (mb.comm != s->stream) {
+            FSA_HIP(hipStreamWaitEvent(s->stream, mb.ev_arrived, 0));
+        }
+        int rc = launch_slab_unpack_hash(s, mb.recv[0], mb.bound_in[0], mb.recv[1], mb.bound_in[1],
                                          mb.mirror + slot * kMirrorInts);
         if (rc) return rc;
         FSA_HIP(hipEventRecord(mb.ev_unpack[slot], s->stream));
-        rc = local_step(s);
+        mb.ahead = false;
+        rc = launch_sort_fused(s, false);
         if (rc) return rc;
-        rc = pack_member(g, mb, msg + 1, true);
+        s->cur = 1 - s->cur;
+        s->hash_valid = s->hash_ahead = false;
+        s->sorted_valid = s->owned_from_sort = s->count_valid = true;
+        s->pd_valid = s->lists_valid = s->hits_valid = false;
+        s->perm_valid = s->index_table_valid = s->ref_cells_valid = false;
+        rc = launch_density(s);
+        if (rc) return rc;
+        // (a member without neighbours has no edges: its forces come in one launch)
+        s->force_zone = (mb.has_left || mb.has_right) ? 1 : 0;
+        rc = launch_force(s);
+        s->force_zone = 0;
+        if (rc) return rc;
+        rc = pack_edges(g, mb, msg + 1, true);
+        if (rc) return rc;
+    }
+    // ---- the records travel; meanwhile the other forces and the second pack pass ----------------------------------
+    int rc = transport(g, msg + 1);
+    if (rc) return rc;
+    for (Member &mb : g.m) {
+        Solver *s = mb.s;
+        FSA_HIP(hipSetDevice(s->device));
+        if (mb.has_left || mb.has_right) {
+            s->force_zone = 2;
+            rc = launch_force(s);
+            s->force_zone = 0;
+            if (rc) return rc;
+        }
+        rc = pack_rest(mb, true);
         if (rc) return rc;
     }
     g.step++;
@@ -316,6 +411,7 @@ int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts
     Group *g = new (std::nothrow) Group();
     if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
     g->kind = 0;
+    g->overlap = overlap_wanted();
     g->world = world;
     g->halo = halo;
     g->record_cap = record_cap;
@@ -356,6 +452,7 @@ int fsa_slab_group_create_rccl(fsa_solver *solver, int rank, int world, const ch
     Group *g = new (std::nothrow) Group();
     if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
     g->kind = 1;
+    g->overlap = overlap_wanted();
     g->world = world;
     g->halo = halo;
     g->record_cap = record_cap;
@@ -399,6 +496,7 @@ int fsa_slab_group_sync(fsa_slab_group *hg, fsa_slab_group_stats *st) {
         Solver *s = mb.s;
         FSA_HIP(hipSetDevice(s->device));
         FSA_HIP(counted_stream_sync(s->stream));
+        if (mb.comm != s->stream) FSA_HIP(counted_stream_sync(mb.comm));
         int vars[8];
         FSA_HIP(hipMemcpy(vars, s->b.slabVars, sizeof(vars), hipMemcpyDeviceToHost));
         s->n = vars[kVarN];
@@ -418,7 +516,8 @@ int fsa_slab_group_sync(fsa_slab_group *hg, fsa_slab_group_stats *st) {
     }
     if (error)
         return fail(FSA_ERR_CAPACITY, "slab group: a count outgrew its buffer (bits %d: 1 solver capacity, 2 / 4 message to the "
-                                      "left / right, 8 / 16 message from the left / right); the state is invalid", error);
+                                      "left / right, 8 / 16 message from the left / right, 32 a particle crossed more than two "
+                                      "cell layers in one step); the state is invalid", error);
     return FSA_OK;
 }
 

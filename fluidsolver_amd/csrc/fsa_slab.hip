@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void slab_init_keys_kernel(int n, const int
 // ---- exchange without host round trips (slab groups, fsa_group.hip) --------------------------------------------
 // (slabVars[]: fsa_solver.h)
 
-// After slab_advect_pack_hash_kernel: the counts leave the atomic counters (which go back to zero for the next
+// After slab_edge_send_kernel: the counts leave the atomic counters (which go back to zero for the next
 // pack), each send buffer gets its count into its header slot, and a copy goes to `mirror` (pinned host memory) for
 // the host to read some steps later.  Counts beyond what the messages take are cut and flagged in
 // slabVars[kVarError]: bits 1 / 2 send buffer left / right.  The particle count stays: nothing has been moved.
@@ -330,68 +330,80 @@ __device__ __forceinline__ void incoming_counts(const long long *hdrLeft, const 
     cr = (int)r;
 }
 
-// The integration, the classification of slab_pack_kernel and the cell hash of the next step in one pass over the
-// slots of the current arrays; nothing moves.  A particle this solver owned at the last sort is integrated (ADVECT;
-// AdvectKernel as in fsa_advect.h) and, by the layer it is in now, stays (its hash and arrival slot are computed,
-// its cell counted), goes out as a record to one or both neighbours, or both.  Every other slot -- halo copies of
-// the last step, particles that left the layers held here -- gets hash kHashDrop, which the sort skips.
-// cellCount must be all zero on entry.
+// Slab groups split the work after the force pass in two, so that the records are on their way while most of the
+// step is still being computed:
+//   edge send   particles that were in a layer next to a cut at the last sort (DevParams::edge) -- the only ones
+//               that can have anything to do with a neighbour -- are integrated in registers (ADVECT; AdvectKernel
+//               as in fsa_advect.h) and written as records to the neighbours whose layers they are in now.  The
+//               arrays stay as they are: the force pass of the other blocks is still reading them;
+//   keep + hash every slot of the current arrays: the particles owned at the last sort are integrated (those of the
+//               first pass once more, to the same bits), and every one that is still inside the layers held here
+//               gets its hash and arrival slot, its cell counted.  Every other slot -- halo copies of the last
+//               step, particles that left the layers held here -- gets hash kHashDrop, which the sort skips.
+//               Nothing moves.  cellCount must be all zero on entry.
+// Before the first sort of a solver nothing tells owned from halo and edge from interior: everything is owned and
+// goes through the edge pass.
+__device__ __forceinline__ void owned_and_edge(const DevParams<float> &P, const SlabRanges &R, int all_owned,
+                                               const int *__restrict__ sortedHash, int i, bool &owned, bool &edge) {
+    owned = edge = all_owned != 0;
+    if (!all_owned) {
+        const unsigned h = (unsigned)sortedHash[i];
+        if (h == FSA_GRID_UNDEF) {
+            owned = true;  // halo copies are always inside the grid when they arrive; such a particle goes nowhere
+        } else {
+            const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
+            owned = gz >= R.own_lo && gz < R.own_hi;
+            edge = owned && layer_in_edge(P, gz);
+        }
+    }
+}
+
+// bit 0 keep, 1 left, 2 right; `lost`: inside the grid but in nobody's layers
+__device__ __forceinline__ unsigned classify(const DevParams<float> &P, const SlabRanges &R, const float4 &p, bool &lost) {
+    lost = false;
+    bool inside = in_domain(P, p.x, p.y, p.z);
+    int cx = 0, cy = 0, cz = 0;
+    if (inside) {
+        calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
+        inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
+    }
+    if (!inside) return 1u;  // out-of-grid particles stay with their owner
+    unsigned flags = 0;
+    if (cz >= R.keep_lo && cz < R.keep_hi) flags |= 1u;
+    if (cz >= R.left_lo && cz < R.left_hi) flags |= 2u;
+    if (cz >= R.right_lo && cz < R.right_hi) flags |= 4u;
+    lost = flags == 0;
+    return flags;
+}
+
 template <bool ADVECT>
-__global__ __launch_bounds__(kBlock) void slab_advect_pack_hash_kernel(
+__global__ __launch_bounds__(kBlock) void slab_edge_send_kernel(
     DevParams<float> P, int bound, int all_owned, SlabRanges R, const int *__restrict__ sortedHash,
-    float4 *__restrict__ posType, float4 *__restrict__ velMass, const Vec3<float> *__restrict__ force,
-    Vec3<float> *__restrict__ v_star, const float *__restrict__ restDensity, const int *__restrict__ uniqueId,
-    const long long *__restrict__ key, SlabRecord<float> *__restrict__ sendLeft, int capLeft,
-    SlabRecord<float> *__restrict__ sendRight, int capRight, int *__restrict__ counters, int *__restrict__ hash,
-    int *__restrict__ slot, int *__restrict__ cellCount, int *__restrict__ undefBlockCount) {
+    const float4 *__restrict__ posType, const float4 *__restrict__ velMass, const Vec3<float> *__restrict__ force,
+    const float *__restrict__ restDensity, const int *__restrict__ uniqueId, const long long *__restrict__ key,
+    SlabRecord<float> *__restrict__ sendLeft, int capLeft, SlabRecord<float> *__restrict__ sendRight, int capRight,
+    int *__restrict__ counters) {
     constexpr int kWaves = kBlock / 64;
-    __shared__ int waveCount[kWaves];
     __shared__ int part[2][kWaves];  // left, right: particles flagged by each wave, then their prefix
     __shared__ int base[2];
     const int n = live_count(P, bound);
     if ((int)blockIdx.x * kBlock >= n) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i < n;
+    bool owned = false, edge = false;
+    if (i < n) owned_and_edge(P, R, all_owned, sortedHash, i, owned, edge);
+    if (!__syncthreads_or(edge ? 1 : 0)) return;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p;
-    unsigned flags = 0;  // bit 0 keep, 1 left, 2 right
-    int lost = 0;
-    if (valid) {
-        bool owned = all_owned != 0;
-        if (!owned) {
-            const unsigned h = (unsigned)sortedHash[i];
-            if (h == FSA_GRID_UNDEF) {
-                owned = true;  // halo copies are always inside the grid when they arrive
-            } else {
-                const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
-                owned = gz >= R.own_lo && gz < R.own_hi;
-            }
+    unsigned flags = 0;
+    if (edge) {
+        p = posType[i];
+        v = velMass[i];
+        if (ADVECT && advect_moves(P, unpack_int(p.w))) {
+            Vec3<float> vs;
+            advect_particle(P, p, v, force[i], vs);
         }
-        if (owned) {
-            p = posType[i];
-            v = velMass[i];
-            if (ADVECT && advect_moves(P, unpack_int(p.w))) {
-                Vec3<float> vs;
-                advect_particle(P, p, v, force[i], vs);
-                v_star[i] = vs;
-                posType[i] = p;
-                velMass[i] = v;
-            }
-            bool inside = in_domain(P, p.x, p.y, p.z);
-            int cx = 0, cy = 0, cz = 0;
-            if (inside) {
-                calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
-                inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
-            }
-            if (!inside) {
-                flags = 1;  // out-of-grid particles stay with their owner
-            } else {
-                if (cz >= R.keep_lo && cz < R.keep_hi) flags |= 1;
-                if (cz >= R.left_lo && cz < R.left_hi) flags |= 2;
-                if (cz >= R.right_lo && cz < R.right_hi) flags |= 4;
-                if (flags == 0) lost = 1;
-            }
-        }
+        bool lost;
+        flags = classify(P, R, p, lost);
     }
     int before[2];
 #pragma unroll
@@ -400,10 +412,7 @@ __global__ __launch_bounds__(kBlock) void slab_advect_pack_hash_kernel(
         before[c] = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) part[c][wave] = __popcll(m);
     }
-    if (lost) atomicAdd(counters + 3, 1);
-    const bool keep = (flags & 1u) != 0;
-    hash_and_count(P, keep, i, p.x, p.y, p.z, hash, slot, cellCount, undefBlockCount, waveCount);  // has a barrier
-    if (valid && !keep) hash[i] = (int)kHashDrop;
+    __syncthreads();
     if (threadIdx.x < 2) {  // exclusive prefix over the waves and one atomic for a block that sends anything
         const int c = threadIdx.x;
         int run = 0;
@@ -431,6 +440,45 @@ __global__ __launch_bounds__(kBlock) void slab_advect_pack_hash_kernel(
             if (at < capRight) sendRight[at] = rec;
         }
     }
+}
+
+// vars[kVarError] bit 5: a particle outside the edge layers ended up in a neighbour's layers (it crossed more than
+// two cell layers in one step); its record was not sent and the run is invalid.
+template <bool ADVECT>
+__global__ __launch_bounds__(kBlock) void slab_keep_hash_kernel(
+    DevParams<float> P, int bound, int all_owned, SlabRanges R, const int *__restrict__ sortedHash,
+    float4 *__restrict__ posType, float4 *__restrict__ velMass, const Vec3<float> *__restrict__ force,
+    Vec3<float> *__restrict__ v_star, int *__restrict__ counters, int *__restrict__ vars, int *__restrict__ hash,
+    int *__restrict__ slot, int *__restrict__ cellCount, int *__restrict__ undefBlockCount) {
+    __shared__ int waveCount[kBlock / 64];
+    const int n = live_count(P, bound);
+    if ((int)blockIdx.x * kBlock >= n) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned flags = 0;
+    if (valid) {
+        bool owned, edge;
+        owned_and_edge(P, R, all_owned, sortedHash, i, owned, edge);
+        if (owned) {
+            p = posType[i];
+            if (ADVECT && advect_moves(P, unpack_int(p.w))) {
+                float4 v = velMass[i];
+                Vec3<float> vs;
+                advect_particle(P, p, v, force[i], vs);
+                v_star[i] = vs;
+                posType[i] = p;
+                velMass[i] = v;
+            }
+            bool lost;
+            flags = classify(P, R, p, lost);
+            if (lost) atomicAdd(counters + 3, 1);
+            if (!edge && (flags & 6u)) atomicOr(vars + kVarError, 32);
+        }
+    }
+    const bool keep = (flags & 1u) != 0;
+    hash_and_count(P, keep, i, p.x, p.y, p.z, hash, slot, cellCount, undefBlockCount, waveCount);
+    if (valid && !keep) hash[i] = (int)kHashDrop;
 }
 
 // Appends the records of both receive buffers (left neighbour's first) behind the slots the arrays hold, with
@@ -605,34 +653,52 @@ int launch_slab_unpack(Solver *s, const void *recs, int count) {
     return FSA_OK;
 }
 
-// The exchange of a group step, sending side (no counts come back to the host).  sendLeft / sendRight are whole
-// send buffers (header slot first); sizeLeft / sizeRight the records this step's messages take.  with_advect: the
-// integration of the step before runs in the same pass.
-int launch_slab_pack_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
-                          const int right[2], void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror) {
+// The exchange of a group step, sending side (no counts come back to the host): the edge pass and the message
+// headers.  sendLeft / sendRight are whole send buffers (header slot first); sizeLeft / sizeRight the records this
+// step's messages take.  with_advect: the integration of the step before runs in the same passes.
+int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const int left[2], const int right[2],
+                          void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror) {
     const int rb = slab_record_bytes(s), c = s->cur, n = s->grid_n();
+    ScopedTimer t(s, "edge_send");
+    SlabRanges R{own[0], own[1], s->pf.z0, s->pf.z0 + s->pf.nz, left[0], left[1], right[0], right[1]};
+    char *l = (char *)sendLeft, *r = (char *)sendRight;
+#define FSA_ES(ADV)                                                                                                  \
+    hipLaunchKernelGGL(slab_edge_send_kernel<ADV>, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->pf, n,        \
+                       s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (const float4 *)s->b.posType[c],              \
+                       (const float4 *)s->b.velMass[c], (const Vec3<float> *)s->b.force,                             \
+                       (const float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c],                       \
+                       (SlabRecord<float> *)(l ? l + rb : nullptr), l ? sizeLeft : 0,                                \
+                       (SlabRecord<float> *)(r ? r + rb : nullptr), r ? sizeRight : 0, s->b.slabCounters)
+    if (n > 0 && (l || r)) {  // (no neighbour, no records)
+        if (with_advect) FSA_ES(true); else FSA_ES(false);
+    }
+#undef FSA_ES
+    hipLaunchKernelGGL(slab_after_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->b.slabCounters, s->b.slabVars,
+                       l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// ... and the pass over everything: who stays, and the hash of the next sort.
+int launch_slab_keep_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
+                          const int right[2]) {
+    const int c = s->cur, n = s->grid_n();
     if (!s->counts_clean) {
         ScopedTimer t(s, "clear_counts");
         FSA_HIP(hipMemsetAsync(s->b.cellCount, 0, (size_t)s->num_cells * sizeof(int), s->stream));
     }
     s->counts_clean = false;
-    ScopedTimer t(s, with_advect ? "advect_pack_hash" : "pack_hash");
+    ScopedTimer t(s, with_advect ? "advect_keep_hash" : "keep_hash");
     SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1]};
-    char *l = (char *)sendLeft, *r = (char *)sendRight;
-#define FSA_APH(ADV)                                                                                                  \
-    hipLaunchKernelGGL(slab_advect_pack_hash_kernel<ADV>, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->pf, n,  \
-                       s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (float4 *)s->b.posType[c],                     \
-                       (float4 *)s->b.velMass[c], (const Vec3<float> *)s->b.force, (Vec3<float> *)s->b.v_star,        \
-                       (const float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c],                        \
-                       (SlabRecord<float> *)(l ? l + rb : nullptr), l ? sizeLeft : 0,                                 \
-                       (SlabRecord<float> *)(r ? r + rb : nullptr), r ? sizeRight : 0, s->b.slabCounters, s->b.hash,  \
-                       s->b.slot, s->b.cellCount, s->b.undefBlockCount)
+#define FSA_KH(ADV)                                                                                                  \
+    hipLaunchKernelGGL(slab_keep_hash_kernel<ADV>, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->pf, n,        \
+                       s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (float4 *)s->b.posType[c],                    \
+                       (float4 *)s->b.velMass[c], (const Vec3<float> *)s->b.force, (Vec3<float> *)s->b.v_star,       \
+                       s->b.slabCounters, s->b.slabVars, s->b.hash, s->b.slot, s->b.cellCount, s->b.undefBlockCount)
     if (n > 0) {
-        if (with_advect) FSA_APH(true); else FSA_APH(false);
+        if (with_advect) FSA_KH(true); else FSA_KH(false);
     }
-#undef FSA_APH
-    hipLaunchKernelGGL(slab_after_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->b.slabCounters, s->b.slabVars,
-                       l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
+#undef FSA_KH
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

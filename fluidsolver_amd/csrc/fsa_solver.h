@@ -120,6 +120,7 @@ struct Solver {
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
+    int force_zone = 0;  // variant-3 force pass: 0 all blocks, 1 only those that touch an edge (DevParams::edge), 2 the rest
     const int *slab_slots = nullptr;  // member of a slab group: number of slots the arrays hold before the sort (the
                                       // sort drops the particles that left; device memory, slabVars[kVarSlots])
     int variant = 3;  // 0 generic, 1 tuned structure + exact arithmetic, 2 tuned structure + fast fp32,
@@ -221,8 +222,10 @@ int launch_slab_keys(Solver *s);
 int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
                      void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
 int launch_slab_unpack(Solver *s, const void *recs, int count);
-int launch_slab_pack_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
-                          const int right[2], void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror);
+int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const int left[2], const int right[2],
+                          void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror);
+int launch_slab_keep_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
+                          const int right[2]);
 int launch_slab_unpack_hash(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
                             int *mirror);
 int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *count);

@@ -387,14 +387,30 @@ __global__ __launch_bounds__(256) void wall_force_kernel(DevParams<float> P, con
         for (int k = 0; k < words; k++) {
             const uint2 w = wp[(size_t)k * BS];
             unsigned m = w.x;
-            while (m) {
-                const int b = __builtin_clz(m);
-                m &= ~(0x80000000u >> b);
-                const int j = (int)w.y + b;
-                const float4 pj = posType[j], vj = velMass[j];
-                const float xx = Sb.p.x - pj.x, xy = Sb.p.y - pj.y, xz = Sb.p.z - pj.z;
-                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, true, vj.w, vj.x, vj.y, vj.z);
+            while (m) {  // four neighbours' loads in flight at a time; the sums stay in neighbour order
+                constexpr int kAhead = 4;
+                int js[kAhead];
+                bool has[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; u++) {
+                    has[u] = m != 0;
+                    const int b = __builtin_clz(m | 1u);
+                    if (has[u]) m &= ~(0x80000000u >> b);
+                    js[u] = has[u] ? (int)w.y + b : i;
+                }
+                float4 pj[kAhead], vj[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; u++) {
+                    pj[u] = posType[js[u]];
+                    vj[u] = velMass[js[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; u++) {
+                    if (!has[u]) continue;
+                    const float xx = Sb.p.x - pj[u].x, xy = Sb.p.y - pj[u].y, xz = Sb.p.z - pj[u].z;
+                    const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                    wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, true, vj[u].w, vj[u].x, vj[u].y, vj[u].z);
+                }
             }
         }
         wallForce[i] = make_float4(Sb.fx, Sb.fy, Sb.fz, 0.f);
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
                                                         const unsigned char *__restrict__ hitCount,
                                                         const unsigned char *__restrict__ wallCount,
                                                         const float4 *__restrict__ wallForce,
-                                                        Vec3<float> *__restrict__ force, int run_log) {
+                                                        Vec3<float> *__restrict__ force, int run_log, int zone) {
     using Shared = RowShared<1, 4, false>;  // only its row table is used here
     __shared__ Shared sh;
     __shared__ Segments sg;
@@ -444,10 +460,14 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
     unsigned hlo = 0, hhi = 0;
-    if (!P.rows || P.nz != P.gres[2]) {  // slab runs: forces are only needed for the layers the solver owns
+    if (!P.rows || P.nz != P.gres[2] || zone) {  // slab runs: forces are only needed for the layers the solver owns
         hlo = (unsigned)sortedHash[b0];
         hhi = (unsigned)sortedHash[b0 + nb - 1];
         if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 0)) return;
+        if (zone) {  // slab groups: the blocks next to the cuts in one launch, the others in a later one
+            const bool edge = hhi == (unsigned)FSA_GRID_UNDEF || run_touches_edge(P, hlo, hhi);
+            if ((zone == 1) != edge) return;
+        }
     }
     ForceSelf<float> S;
     S.p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -670,18 +690,19 @@ int launch_force_fast(Solver *s) {
         int rc = launch_density_record<false>(s);
         if (rc) return rc;
     }
-    const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
-    {
+    const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8), zone = s->force_zone;
+    if (zone != 2) {  // (zone 2 follows zone 1, which has run it)
         ScopedTimer t(s, "wall_force");
         hipLaunchKernelGGL((wall_force_kernel<kTunedBS>), dim3(1024), dim3(256), 0, s->stream, s->pf, s->b.wallList,
                            (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                            (const uint2 *)s->b.hitWords, s->b.wallCount, (float4 *)s->b.wallForce);
     }
-    ScopedTimer t(s, "force");
+    ScopedTimer t(s, zone == 1 ? "force_edge" : "force");
     hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, s->xcd_run_log)), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                        (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
-                       s->b.hitCount, s->b.wallCount, (const float4 *)s->b.wallForce, (Vec3<float> *)s->b.force, run_log);
+                       s->b.hitCount, s->b.wallCount, (const float4 *)s->b.wallForce, (Vec3<float> *)s->b.force, run_log,
+                       zone);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

@@ -632,7 +632,7 @@ def _bench_distributed(args, build_scene):
     local_n = ss.backend.n
     types = ss.backend.get("type")
     local_fluid = int((types == 0).sum())
-    exch_ms = sum(ms for k, (c, ms) in kt.items() if k in ("slab_pack", "pack_hash", "exchange", "slab_unpack", "unpack_hash")) / max(args.steps, 1)
+    exch_ms = sum(ms for k, (c, ms) in kt.items() if k in ("slab_pack", "edge_send", "exchange", "slab_unpack", "unpack_hash")) / max(args.steps, 1)
     stats = torch.tensor([wall, float(local_n), float(lost), float(ss.backend.solver.num_undef()), float(sent),
                           exch_ms, float(host_waits)], dtype=torch.float64, device=sync_dev)
     mx = stats.clone()

@@ -10,9 +10,14 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="dam16m"); ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--spinup", type=int, default=100)
+ap.add_argument("--dims", type=int, nargs=3, default=None, help="dam break of nx ny nz particles instead of --scene")
 ap.add_argument("--show", type=int, default=-1, help="slab whose kernel times are printed (default: the middle one)")
 a = ap.parse_args()
-sc = bench.build_scene(a.scene, 0.0)
+if a.dims:
+    from fluidsolver_amd import scenes
+    sc = scenes.dam_break(*a.dims)
+else:
+    sc = bench.build_scene(a.scene, 0.0)
 ranks = [slabs.SlabSolver(sc, r, a.world, None, lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, 3),
                           exchange_buffers=False) for r in range(a.world)]
 g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
