@@ -59,10 +59,12 @@ def parse():
 SCENES = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64), "ddam64m": (320, 320, 320)}
 
 
-def build_scene(name, jitter=0.0):
+def build_scene(name, jitter=0.0, z_select=None):
+    """`z_select`: build only the particles whose z coordinate it selects (fluidsolver_amd/scenes.py)"""
     from fluidsolver_amd import scenes
     nx, ny, nz = SCENES[name]
-    sc = scenes.double_dam_break(nx, ny, nz) if name == "ddam64m" else scenes.dam_break(nx, ny, nz)
+    sc = scenes.double_dam_break(nx, ny, nz, z_select=z_select) if name == "ddam64m" else \
+        scenes.dam_break(nx, ny, nz, z_select=z_select)
     if jitter > 0:
         n_fluid = sc["n_fluid"]
         sc = scenes.jittered(sc, seed=2024, pos_jitter=jitter, vel_scale=0.0, fluid_only=True)

@@ -11,6 +11,11 @@ A scene is a dict of numpy arrays in upload order:
   type (n,) i32, group (n,) i32, uniqueId (n,) i32, mass (n,) f32,
   restDensity (n,) f32
 plus 'params' (keyword arguments for the solver parameter block).
+
+Windows.  The generators of the benchmark scenes take `z_select`, a function from an array of z coordinates to a
+boolean mask: only the selected particles are built (a rank of a z-slab run builds its own layers, not the scene),
+with the unique ids they have in the whole scene; 'n_total' is then the size of the whole scene and
+'z_counts' = (z values, particles per value) of the whole scene, from which the layer histogram follows.
 """
 from __future__ import annotations
 
@@ -57,6 +62,13 @@ def _grid3(ax, ay, az) -> np.ndarray:
 
 def _finish(parts, params) -> dict:
     n = sum(len(p["pos"]) for p in parts)
+    # AddDefaultParticle: unique_id = index at creation, MultiphaseSPHSolver.cpp:489 (a windowed part knows which
+    # of its indices it kept)
+    uid, base = [], 0
+    for p in parts:
+        local = p.get("uid_local")
+        uid.append(base + (np.arange(len(p["pos"]), dtype=np.int64) if local is None else local))
+        base += p.get("n_full", len(p["pos"]))
     sc = {
         "pos": np.concatenate([p["pos"] for p in parts]).astype(F32),
         "vel": np.zeros((n, 3), F32),
@@ -66,22 +78,51 @@ def _finish(parts, params) -> dict:
         "group": np.concatenate([np.full(len(p["pos"]), p.get("group", 0), np.int32) for p in parts]),
         "mass": np.concatenate([np.full(len(p["pos"]), p["mass"], F32) for p in parts]),
         "restDensity": np.concatenate([np.full(len(p["pos"]), p["restDensity"], F32) for p in parts]),
-        # AddDefaultParticle: unique_id = index at creation, MultiphaseSPHSolver.cpp:489
-        "uniqueId": np.arange(n, dtype=np.int32),
+        "uniqueId": np.concatenate(uid).astype(np.int32) if parts else np.zeros(0, np.int32),
         "params": params,
+        "n_total": int(base),
     }
+    zs = [p["z_counts"] for p in parts if "z_counts" in p]
+    if len(zs) == len(parts) and parts:
+        sc["z_counts"] = (np.concatenate([z for z, _ in zs]), np.concatenate([c for _, c in zs]))
     return sc
 
 
-def fluid_block(xmin, xmax, spacing, density, color=(1, 1, 1, 1), group=0, ptype=TYPE_FLUID) -> dict:
+def fluid_block(xmin, xmax, spacing, density, color=(1, 1, 1, 1), group=0, ptype=TYPE_FLUID, z_select=None) -> dict:
     """Solid block branch of AddMultiphaseFluidVolumes, MultiphaseSPHSolver.cpp:714-735.
     mass = spacing^3 * density in fp32 (:539)."""
     s = F32(spacing)
-    pos = _grid3(lattice_axis(xmin[0], xmax[0], s), lattice_axis(xmin[1], xmax[1], s),
-                 lattice_axis(xmin[2], xmax[2], s))
+    ax, ay, az = (lattice_axis(xmin[a], xmax[a], s) for a in range(3))
     mass = F32(F32(F32(s * s) * s) * F32(density))
-    return {"pos": pos, "type": ptype, "mass": mass, "restDensity": F32(density), "group": group,
-            "color": np.tile(np.asarray(color, F32), (len(pos), 1))}
+    out = {"type": ptype, "mass": mass, "restDensity": F32(density), "group": group,
+           "z_counts": (az, np.full(len(az), len(ax) * len(ay), np.int64))}
+    if z_select is not None:
+        kz = np.nonzero(z_select(az))[0]
+        nx, ny, nz = len(ax), len(ay), len(az)
+        out["n_full"] = nx * ny * nz
+        # index of lattice point (ix, iy, iz) in the whole block: x outermost, z innermost
+        out["uid_local"] = ((np.arange(nx, dtype=np.int64)[:, None, None] * ny + np.arange(ny, dtype=np.int64)[None, :, None])
+                            * nz + kz[None, None, :]).reshape(-1)
+        az = az[kz]
+    out["pos"] = _grid3(ax, ay, az)
+    out["color"] = np.tile(np.asarray(color, F32), (len(out["pos"]), 1))
+    return out
+
+
+def _window(part, z_select) -> dict:
+    """The selected particles of a part that was built whole (walls and obstacles: a thin shell of the scene)."""
+    z = part["pos"][:, 2]
+    vals, counts = np.unique(z, return_counts=True)
+    part["z_counts"] = (vals.astype(F32), counts.astype(np.int64))
+    if z_select is None:
+        return part
+    keep = np.nonzero(z_select(z))[0]
+    part["n_full"] = len(z)
+    part["uid_local"] = keep.astype(np.int64)
+    for k in ("pos", "normal", "color"):
+        if k in part:
+            part[k] = part[k][keep]
+    return part
 
 
 def open_box(xmin, xmax, spacing, group=1, ptype=TYPE_RIGID, lid=False, mass=0.0, rest_density=0.0) -> dict:
@@ -190,24 +231,24 @@ def dam_break_geometry(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.0
 
 
 def dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, wall_type=TYPE_BOUNDARY, spacing=0.005,
-              boundary_mode=1, walls=True) -> dict:
+              boundary_mode=1, walls=True, z_select=None) -> dict:
     """Benchmark dam break: an nx*ny*nz fluid lattice (rest density 1000) standing in one corner of
     a tank `tank_x_factor` times as long in x.  Tank walls and floor are one layer of wall particles
     (TYPE_BOUNDARY, so ForceCell's penalty branch acts) placed two cells inside the grid box;
     boundary_mode 1 adds the legacy clamp to the grid box as a safety net."""
     s = F32(spacing)
     g = dam_break_geometry(nx, ny, nz, tank_x_factor, head_room, spacing, boundary_mode)
-    fluid = fluid_block(g["fluid_lo"], g["fluid_hi"], s, 1000.0, color=(0.2, 0.4, 1, 1))
+    fluid = fluid_block(g["fluid_lo"], g["fluid_hi"], s, 1000.0, color=(0.2, 0.4, 1, 1), z_select=z_select)
     parts = [fluid]
     if walls:
-        parts.append(open_box(g["tank_lo"], g["tank_hi"], s, group=1, ptype=wall_type,
-                              mass=rigid_mass(s, 1000.0), rest_density=1000.0))
+        parts.append(_window(open_box(g["tank_lo"], g["tank_hi"], s, group=1, ptype=wall_type,
+                                      mass=rigid_mass(s, 1000.0), rest_density=1000.0), z_select))
     sc = _finish(parts, g["params"])
-    sc["n_fluid"] = len(fluid["pos"])
+    sc["n_fluid"] = fluid.get("n_full", len(fluid["pos"]))  # of the whole scene
     return sc
 
 
-def double_dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.005, obstacles=2) -> dict:
+def double_dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.005, obstacles=2, z_select=None) -> dict:
     """Double dam break in small: two nx*ny*nz fluid blocks at the two x ends of the tank and `obstacles`
     box obstacles between them (filled TYPE_BOUNDARY lattices, the generator of BoundaryGenerator 'Cube',
     solver/ParticleGenerator.h:27-43), staggered in z so that the flow is not symmetric along z."""
@@ -216,21 +257,21 @@ def double_dam_break(nx, ny, nz, tank_x_factor=4.0, head_room=1.5, spacing=0.005
     lo, hi = np.array(g["fluid_lo"]), np.array(g["fluid_hi"])
     tank = np.array(g["tank_hi"])
     ext = hi - lo
-    a = fluid_block(lo, hi, s, 1000.0, color=(0.2, 0.4, 1, 1), group=0)
+    a = fluid_block(lo, hi, s, 1000.0, color=(0.2, 0.4, 1, 1), group=0, z_select=z_select)
     shift = np.array([tank[0] - 2 * lo[0] - (nx - 1) * float(s), 0.0, 0.0])
-    b = fluid_block(lo + shift, hi + shift, s, 1000.0, color=(1, 0.4, 0.2, 1), group=1)
-    parts = [a, b, open_box(g["tank_lo"], g["tank_hi"], s, group=2, ptype=TYPE_BOUNDARY,
-                            mass=rigid_mass(s, 1000.0), rest_density=1000.0)]
+    b = fluid_block(lo + shift, hi + shift, s, 1000.0, color=(1, 0.4, 0.2, 1), group=1, z_select=z_select)
+    parts = [a, b, _window(open_box(g["tank_lo"], g["tank_hi"], s, group=2, ptype=TYPE_BOUNDARY,
+                                    mass=rigid_mass(s, 1000.0), rest_density=1000.0), z_select)]
     side = max(4 * float(s), 0.15 * ext[2])
     for k in range(obstacles):
         cx = tank[0] * (k + 1) / (obstacles + 1)
         cz = lo[2] + ext[2] * (0.25 if k % 2 == 0 else 0.75)
         o_lo = (cx - side / 2, lo[1], cz - side / 2)
         o_hi = (cx + side / 2, lo[1] + 0.5 * ext[1], cz + side / 2)
-        parts.append(cube(o_lo, o_hi, s, normal=(0, 1, 0), group=3 + k, ptype=TYPE_BOUNDARY,
-                          mass=rigid_mass(s, 1000.0), rest_density=1000.0))
+        parts.append(_window(cube(o_lo, o_hi, s, normal=(0, 1, 0), group=3 + k, ptype=TYPE_BOUNDARY,
+                                  mass=rigid_mass(s, 1000.0), rest_density=1000.0), z_select))
     sc = _finish(parts, g["params"])
-    sc["n_fluid"] = len(a["pos"]) + len(b["pos"])
+    sc["n_fluid"] = a.get("n_full", len(a["pos"])) + b.get("n_full", len(b["pos"]))  # of the whole scene
     return sc
 
 

@@ -47,6 +47,17 @@ def cell_layer_host(pos, vmin, vmax, dx, gridres):
     return np.where(inside, cell[2], -1)
 
 
+def z_layer_host(z, vmin_z, vmax_z, dx, gz):
+    """cell_layer_host for z coordinates alone (positions known to be inside the grid box in x and y)."""
+    z = np.asarray(z, dtype=np.float32)
+    f32 = np.float32
+    z64 = z.astype(np.float64)
+    inside = (z64 < float(f32(vmax_z)) - 1e-10) & (z64 > float(f32(vmin_z)) + 1e-10)
+    cell = np.floor((z - f32(vmin_z)) / f32(dx)).astype(np.int64)
+    inside &= (cell >= 0) & (cell < gz)
+    return np.where(inside, cell, -1)
+
+
 def balanced_cuts(layer_counts, nranks, min_layers=HALO + 1):
     """Cut indices c[0..nranks] (c[0] = 0, c[-1] = number of layers) that balance the particle counts,
     every slab at least `min_layers` thick."""
@@ -310,7 +321,9 @@ class SlabSolver:
     solver (HipSlabBackend on a GPU); `transport` moves records between ranks."""
 
     def __init__(self, scene, rank, world, transport, backend_factory, halo=HALO, slack=1.5, cuts=None,
-                 exchange_buffers=True):
+                 exchange_buffers=True, layer_hist=None, has_rigid=None):
+        """`scene` is the whole scene, or (with `layer_hist`, the particles per cell layer of the whole scene) at
+        least the particles of the layers this rank owns, carrying their unique ids of the whole scene."""
         P = scene["params"]
         self.rank, self.world, self.transport = rank, world, transport
         pos = np.asarray(scene["pos"], dtype=np.float32)
@@ -319,7 +332,7 @@ class SlabSolver:
         self.gridres, self.dx = geo["gridres"], geo["dx"]
         gz = self.gridres[2]
         layer = cell_layer_host(pos, geo["vmin"], geo["vmax"], self.dx, self.gridres)
-        hist = np.bincount(layer[layer >= 0], minlength=gz)
+        hist = np.bincount(layer[layer >= 0], minlength=gz) if layer_hist is None else np.asarray(layer_hist)
         if cuts is None:
             cuts = balanced_cuts(hist, world, halo + 1) if world > 1 else [0, gz]
         self.layout = SlabLayout(gz, cuts, halo)
@@ -338,7 +351,8 @@ class SlabSolver:
         self.record_cap = int(widest * slack) + 4096
         self.params, self.factory, self.halo, self.slack = P, backend_factory, halo, slack
         self.geo = geo
-        self.has_rigid = bool((np.asarray(scene["type"]) == 4).any())
+        # (of the whole scene: a rank that was given its own particles only is told)
+        self.has_rigid = bool((np.asarray(scene["type"]) == 4).any()) if has_rigid is None else bool(has_rigid)
         self.backend = backend_factory(P, held, self.capacity)
         uid = np.asarray(scene.get("uniqueId", np.arange(len(pos))), dtype=np.int32)
         sub = {k: np.ascontiguousarray(np.asarray(scene[k])[mine]) for k in ("pos", "vel", "type", "mass",
@@ -541,16 +555,38 @@ def _bench_distributed(args, build_scene):
         if not all(oks):
             record_group, use_nccl = None, False
     backend = "nccl" if use_nccl else "gloo"
-    sc = build_scene(args.scene, args.jitter)
-    n, n_fluid = len(sc["pos"]), sc["n_fluid"]
+    # Every rank builds the particles of its own layers only: first the scene's per-layer histogram (the fluid
+    # lattice contributes one count per z value, the walls are a thin shell), from it the cuts, then the window.
+    # (A jittered scene draws its noise for the whole scene in one stream: built whole.)
+    layer_hist, cuts0 = None, None
+    if args.jitter > 0:
+        sc = build_scene(args.scene, args.jitter)
+        n = len(sc["pos"])
+    else:
+        probe = build_scene(args.scene, 0.0, z_select=lambda z: np.zeros(len(z), bool))
+        geo = derive_grid(probe["params"])
+        gz = geo["gridres"][2]
+        layer_of = lambda z: z_layer_host(z, geo["vmin"][2], geo["vmax"][2], geo["dx"], gz)  # noqa: E731
+        zv, zc = probe["z_counts"]
+        lay = layer_of(zv)
+        assert (lay >= 0).all(), "the generated scenes lie inside the grid box"
+        layer_hist = np.bincount(lay, weights=zc, minlength=gz).astype(np.int64)
+        cuts0 = balanced_cuts(layer_hist, world, HALO + 1) if world > 1 else [0, gz]
+        lo, hi = cuts0[rank], cuts0[rank + 1]
+        sc = build_scene(args.scene, 0.0, z_select=lambda z: (layer_of(z) >= lo) & (layer_of(z) < hi))
+        n = sc["n_total"]
+    n_fluid = sc["n_fluid"]
     transport = NeighbourTransport(rank, world, device, group=record_group)
     # With a GPU per rank the step runs in the library's slab group: pack, ncclSend / ncclRecv, unpack and the
     # solver's step queued without a host round trip.  Ranks sharing a card (rehearsal) keep the torch transport.
-    native = use_nccl and os.environ.get("FSA_SLAB_NATIVE", "1") != "0" and \
-        not bool((np.asarray(sc["type"]) == 4).any()) and (args.variant is None or args.variant == 3)
+    rigid = torch.tensor([int((np.asarray(sc["type"]) == 4).any())])
+    dist.all_reduce(rigid, op=dist.ReduceOp.MAX)  # the ranks hold different parts of the scene and must agree
+    has_rigid = bool(rigid.item())
+    native = use_nccl and os.environ.get("FSA_SLAB_NATIVE", "1") != "0" and not has_rigid and \
+        (args.variant is None or args.variant == 3)
     ss = SlabSolver(sc, rank, world, transport,
                     lambda P, held, cap: HipSlabBackend(P, held, cap, device_index, args.variant),
-                    exchange_buffers=not native)
+                    exchange_buffers=not native, cuts=cuts0, layer_hist=layer_hist, has_rigid=has_rigid)
     del sc
     sync_dev = torch.device("cpu")
     from . import capi
@@ -611,8 +647,8 @@ def _bench_distributed(args, build_scene):
     recuts0, sent0 = ss.recuts, ss.sent_records
     if native:
         run.sent = -int(group.sync().records_sent)
-    host_waits0 = capi.load().fsa_debug_host_waits()
     barrier()
+    host_waits0 = capi.load().fsa_debug_host_waits()
     t0 = time.perf_counter()
     run(args.steps)
     host_waits = capi.load().fsa_debug_host_waits() - host_waits0

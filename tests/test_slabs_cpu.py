@@ -153,3 +153,48 @@ def test_layout_ranges():
     assert lay.own(1) == (7, 13) and lay.held(1) == (5, 15)
     assert lay.held(0) == (0, 9) and lay.held(2) == (11, 20)
     assert lay.held(-1) == (0, 0) and lay.held(3) == (0, 0)
+
+
+def test_windowed_scene_gives_each_rank_its_particles_of_the_whole_scene():
+    """a rank that builds only the particles of its own layers (scenes.*(z_select=...)) uploads exactly what it
+    would take from the whole scene, unique ids included, and sizes its buffers the same"""
+    from fluidsolver_amd import scenes
+
+    class Capture:
+        record_bytes = 48
+
+        def __init__(self, P, held, cap):
+            self.held, self.cap = held, cap
+
+        def upload(self, sub):
+            self.sub = sub
+
+        def set_scene_has_rigid(self, flag):
+            self.rigid = flag
+
+        def set_owned(self, own):
+            self.own = own
+
+    whole = scenes.double_dam_break(8, 8, 20, tank_x_factor=3.0)
+    probe = scenes.double_dam_break(8, 8, 20, tank_x_factor=3.0, z_select=lambda z: np.zeros(len(z), bool))
+    assert len(probe["pos"]) == 0 and probe["n_total"] == len(whole["pos"]) and probe["n_fluid"] == whole["n_fluid"]
+    geo = slabs.derive_grid(whole["params"])
+    gz = geo["gridres"][2]
+    layer_of = lambda z: slabs.z_layer_host(z, geo["vmin"][2], geo["vmax"][2], geo["dx"], gz)  # noqa: E731
+    zv, zc = probe["z_counts"]
+    hist = np.bincount(layer_of(zv), weights=zc, minlength=gz).astype(np.int64)
+    full_layers = slabs.cell_layer_host(whole["pos"], geo["vmin"], geo["vmax"], geo["dx"], geo["gridres"])
+    assert np.array_equal(hist, np.bincount(full_layers, minlength=gz))
+    world = 3
+    cuts = slabs.balanced_cuts(hist, world)
+    for r in range(world):
+        lo, hi = cuts[r], cuts[r + 1]
+        part = scenes.double_dam_break(8, 8, 20, tank_x_factor=3.0,
+                                       z_select=lambda z: (layer_of(z) >= lo) & (layer_of(z) < hi))
+        a = slabs.SlabSolver(whole, r, world, None, Capture, exchange_buffers=False)
+        b = slabs.SlabSolver(part, r, world, None, Capture, exchange_buffers=False, cuts=cuts, layer_hist=hist,
+                             has_rigid=False)
+        assert a.layout.cuts == b.layout.cuts and a.capacity == b.capacity and a.record_cap == b.record_cap
+        assert sorted(a.backend.sub) == sorted(b.backend.sub)
+        for k in a.backend.sub:
+            assert np.array_equal(a.backend.sub[k], b.backend.sub[k]), k
