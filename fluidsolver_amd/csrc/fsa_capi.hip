@@ -636,7 +636,7 @@ int fsa_step(fsa_solver *hs, int nsteps) {
         }
         return FSA_OK;
     }
-    // Seven launches per step: the integration computes the next step's hash and counts on the way, the two
+    // Eight launches per step (seven plus the wall pass): the integration computes the next step's hash and counts on the way, the two
     // prefix sums share two launches, the rank pass moves the particles and writes the row table.
     for (int k = 0; k < nsteps; k++) {
         if (!s->hash_valid && !s->hash_ahead) TRY(launch_hash_fused(s, false));

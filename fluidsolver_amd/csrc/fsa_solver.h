@@ -115,6 +115,7 @@ struct Solver {
     bool use_lists = true;      // passes that repeat between two sorts replay recorded neighbour lists
     bool lists_valid = false;   // nbList / nbCount describe the current arrays and positions
     bool hits_valid = false;    // hitWords / hitCount describe the current arrays and positions
+    bool wall_list_clean = false;  // wallList[0] is zero (the variant-3 force pass resets it once the wall pass has run)
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]

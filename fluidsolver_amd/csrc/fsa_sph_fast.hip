@@ -444,6 +444,7 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
                                                         const unsigned char *__restrict__ hitCount,
                                                         const unsigned char *__restrict__ wallCount,
                                                         const float4 *__restrict__ wallForce,
+                                                        int *__restrict__ wallList,
                                                         Vec3<float> *__restrict__ force, int run_log, int zone) {
     using Shared = RowShared<1, 4, false>;  // only its row table is used here
     __shared__ Shared sh;
@@ -453,6 +454,8 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
     const int dbg = run_log >> 8;
     run_log &= 255;
     const int quorum = (dbg >> 4) ? (dbg >> 4) : 40;
+    // the wall pass has run: its list starts empty at the next density pass (Solver::wall_list_clean)
+    if (blockIdx.x == 0 && threadIdx.x == 0) wallList[0] = 0;
     n = live_count(P, n);
     const int blk = xcd_block(run_log);
     const int b0 = blk * BS;
@@ -661,7 +664,9 @@ static inline int tiled_grid(const Solver *s, int run_log) {
 
 template <bool EVAL> static int launch_density_record(Solver *s) {
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
-    FSA_HIP(hipMemsetAsync(s->b.wallList, 0, sizeof(int), s->stream));  // the list of the wall pass starts empty
+    if (!s->wall_list_clean)  // the list of the wall pass starts empty (the force pass leaves it so)
+        FSA_HIP(hipMemsetAsync(s->b.wallList, 0, sizeof(int), s->stream));
+    s->wall_list_clean = false;
     hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, s->xcd_run_log)),
                        dim3(kTunedBS), 0, s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c],
                        (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
@@ -701,9 +706,10 @@ int launch_force_fast(Solver *s) {
     hipLaunchKernelGGL((force_rows_kernel<kTunedBS, kRowCap>), dim3(tiled_grid(s, s->xcd_run_log)), dim3(kTunedBS), 0,
                        s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],
                        (const float2 *)s->b.pd, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
-                       s->b.hitCount, s->b.wallCount, (const float4 *)s->b.wallForce, (Vec3<float> *)s->b.force, run_log,
-                       zone);
+                       s->b.hitCount, s->b.wallCount, (const float4 *)s->b.wallForce, s->b.wallList,
+                       (Vec3<float> *)s->b.force, run_log, zone);
     FSA_HIP(hipGetLastError());
+    s->wall_list_clean = true;
     return FSA_OK;
 }
 

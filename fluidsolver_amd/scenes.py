@@ -80,10 +80,10 @@ def _finish(parts, params) -> dict:
         "restDensity": np.concatenate([np.full(len(p["pos"]), p["restDensity"], F32) for p in parts]),
         "uniqueId": np.concatenate(uid).astype(np.int32) if parts else np.zeros(0, np.int32),
         "params": params,
-        "n_total": int(base),
     }
-    zs = [p["z_counts"] for p in parts if "z_counts" in p]
-    if len(zs) == len(parts) and parts:
+    if any("n_full" in p for p in parts):  # a windowed scene says what the whole one looks like
+        sc["n_total"] = int(base)
+        zs = [p["z_counts"] for p in parts]
         sc["z_counts"] = (np.concatenate([z for z, _ in zs]), np.concatenate([c for _, c in zs]))
     return sc
 
