@@ -413,8 +413,8 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(int n, const int
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const unsigned h = (unsigned)hash[i];
+    const int sl = slot[i];      // (both loads in flight before the test)
     if (h == kHashDrop) return;  // the particle has left this solver (fsa_hash.h)
-    const int sl = slot[i];
     int p;
     if (h != FSA_GRID_UNDEF) {
         const int a = cellStart[h];
