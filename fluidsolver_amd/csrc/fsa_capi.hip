@@ -829,6 +829,9 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     s->pd_valid = false;  // density, pressure, mass or viscosity may change under it
     s->lists_valid = false;
     s->hits_valid = false;
+    // a member of a slab group: its next step is already prepared from the old values (records on their way to
+    // the neighbours); the group notices by this flag and refuses to go on
+    if (s->pf.count) s->hash_ahead = false;
     auto plain = [&](void *ddst, size_t expect) -> int {
         TRY(want(expect));
         if (bytes) FSA_HIP(hipMemcpy(ddst, src, bytes, hipMemcpyHostToDevice));

@@ -382,10 +382,16 @@ int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
 /* ---- z-slab groups: the whole slab step, exchange included, without a host round trip ------------------
  *
  * Replaces the step loop of main.cpp:11-19 -> MultiphaseSPHSolver::Step (solver/MultiphaseSPHSolver.cpp:199-217)
- * for a scene cut into z-slabs.  A group drives, per step and per slab: fsa_slab_pack's classification ->
- * transport -> append -> hash, sort, density, force, integration, all queued on the solvers' streams.  The
- * particle counts stay in device memory (they change with every exchange): fsa_slab_group_step returns
- * without waiting, and any other entry point called on a member solver first waits for the queued steps.
+ * for a scene cut into z-slabs.  A group drives, per step and per slab: append what the neighbours sent -> sort
+ * (which drops the halo copies of the step before and the particles that left) -> density -> force ->
+ * integration, fsa_slab_pack's classification and the records for the neighbours -> transport, all queued on the
+ * solvers' streams; the particles that stay are never copied for the exchange.  The force pass handles the blocks
+ * next to the cuts first, so that the records of the next step travel (on a stream of the group's own) while the
+ * rest of the step is computed; FSA_SLAB_OVERLAP=0 in the environment when the group is made keeps everything on
+ * the solver's stream.  The particle counts stay in device memory (they change with every exchange):
+ * fsa_slab_group_step returns without waiting, and any other entry point called on a member solver first waits for
+ * the queued steps.  Between two fsa_slab_group_step calls a member's particles may be read, not changed (upload,
+ * parameter changes, the solver's own step): the next call then fails with FSA_ERR_INVALID.
  * Members must be fp32 slab solvers on kernel variant 3 whose scene has no TYPE_RIGID particles; each must hold
  * exactly the layers [cuts[r] - halo, cuts[r+1] + halo) (clipped to the grid) of its rank r.
  *
@@ -399,7 +405,8 @@ int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
  * Messages are sized from the counts of three steps earlier plus head room (record_cap = the most records one
  * message may ever carry).  If a count outgrows its message or a solver's capacity, the excess is dropped,
  * flagged on the device, and fsa_slab_group_sync (or the next entry point used on the solver) returns
- * FSA_ERR_CAPACITY: the state is then invalid.
+ * FSA_ERR_CAPACITY: the state is then invalid.  The same happens when a particle crosses more than two cell layers
+ * in one step next to a cut (only the particles of the halo + 2 layers next to a cut are looked at for sending).
  */
 typedef struct fsa_slab_group fsa_slab_group;
 #define FSA_SLAB_GROUP_ID_BYTES 128
@@ -409,7 +416,8 @@ typedef struct fsa_slab_group_stats {
     long long max_particles; /* the largest member */
     long long lost;          /* particles that left every range they could go to (no neighbour holds their layer) */
     long long records_sent;  /* by this process's members, up to three steps ago */
-    int error_bits;          /* 0, or what overflowed: 1 capacity, 2/4 message out left/right, 8/16 in left/right */
+    int error_bits;          /* 0, or what overflowed: 1 capacity, 2/4 message out left/right, 8/16 in left/right,
+                                32 a particle crossed more than two cell layers in one step */
 } fsa_slab_group_stats;
 int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts /* world + 1 */, int halo,
                                 int record_cap, fsa_slab_group **out);

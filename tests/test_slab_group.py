@@ -137,3 +137,65 @@ def test_rccl_group_single_rank_and_loopback():
     assert torch.equal(src, dst)
     g.close()
     ss.close()
+
+
+def test_group_without_overlap_gives_the_same_bits(monkeypatch):
+    """FSA_SLAB_OVERLAP=0 (read when the group is made): transport on the solver's stream, same results"""
+    monkeypatch.setenv("FSA_SLAB_OVERLAP", "0")
+    sc = SCENES["ddam"]()
+    ranks = make_ranks(sc, 3)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    g.step(STEPS)
+    st = g.sync()
+    assert st.lost == 0 and st.error_bits == 0
+    uid, got = merged([ss.owned() for ss in ranks])
+    assert_same_bits(uid, got, plain_gpu_run(sc, STEPS, 3))
+    g.close()
+    for ss in ranks:
+        ss.close()
+
+
+def test_group_reports_a_particle_that_jumps_layers():
+    """a particle far from the cuts that lands in a neighbour's layers within one step was not looked at when the
+    records were written: the group flags it (error bit 32) instead of losing it silently"""
+    sc = SCENES["dam"]()
+    geo = slabs.derive_grid(sc["params"])
+    ranks = make_ranks(sc, 2)
+    cut = ranks[0].layout.cuts[1]
+    # a fluid particle of rank 0, at least five layers below the cut, thrown across it
+    layer = slabs.cell_layer_host(sc["pos"], geo["vmin"], geo["vmax"], geo["dx"], geo["gridres"])
+    cand = np.nonzero((sc["type"] == 0) & (layer < cut - 5) & (layer >= 0))[0]
+    assert len(cand)
+    i = cand[0]
+    dist = (cut + 1 - layer[i]) * float(geo["dx"])
+    sc = dict(sc)
+    sc["vel"] = sc["vel"].copy()
+    sc["vel"][i] = (0.0, 0.0, dist / sc["params"]["dt"])
+    for ss in ranks:
+        ss.close()
+    ranks = make_ranks(sc, 2)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    g.step(2)  # the first pack (before any sort) sends everything through the edge pass; the second one does not
+    with pytest.raises(capi.FsaError, match="crossed more than two"):
+        g.sync()
+    g.close()
+    for ss in ranks:
+        ss.close()
+
+
+def test_group_refuses_members_changed_between_steps():
+    sc = SCENES["dam"]()
+    ranks = make_ranks(sc, 2)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    g.step(3)
+    g.sync()
+    s0 = ranks[0].backend.solver
+    s0.set("vel", s0.get("vel"))  # any change of the particles invalidates what the group has prepared
+    with pytest.raises(capi.FsaError, match="changed between two steps"):
+        g.step(1)
+    g.close()
+    for ss in ranks:
+        ss.close()
