@@ -115,6 +115,10 @@ struct Solver {
     bool use_lists = true;      // passes that repeat between two sorts replay recorded neighbour lists
     bool lists_valid = false;   // nbList / nbCount describe the current arrays and positions
     bool hits_valid = false;    // hitWords / hitCount describe the current arrays and positions
+    int wall_mode = 0;             // where the variant-3 passes sum the wall neighbours: 0 by size (fsa_sph_fast.hip), 1 in
+                                   // the density pass's tail, 2 in a pass of their own; FSA_WALL_PASS=0 / 1, read once by
+                                   // fsa_create, forces the tail / the pass
+    bool wall_listed = false;      // the last record listed its wall particles: the wall pass has to run
     bool wall_list_clean = false;  // wallList[0] is zero (the variant-3 force pass resets it once the wall pass has run)
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)

@@ -31,6 +31,50 @@
 
 namespace fsa {
 
+// The wall words of particle i (at `wp`, stride BS), summed in neighbour order.
+template <int BS>
+__device__ __forceinline__ float4 wall_sum(const DevParams<float> &P, int i, const uint2 *__restrict__ wp, int words,
+                                           const float4 *__restrict__ posType, const float4 *__restrict__ velMass) {
+    const float sr = P.sr, sr2 = sr * sr;
+    const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
+    const WallConsts W(P);
+    ForceSelf<float> Sb;
+    Sb.p = posType[i];
+    Sb.v = velMass[i];
+    Sb.pterm = 0.f;
+    Sb.fx = Sb.fy = Sb.fz = 0.f;
+    for (int k = 0; k < words; k++) {
+        const uint2 w = wp[(size_t)k * BS];
+        unsigned m = w.x;
+        while (m) {  // four neighbours' loads in flight at a time; the sums stay in neighbour order
+            constexpr int kAhead = 4;
+            int js[kAhead];
+            bool has[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) {
+                has[u] = m != 0;
+                const int b = __builtin_clz(m | 1u);
+                if (has[u]) m &= ~(0x80000000u >> b);
+                js[u] = has[u] ? (int)w.y + b : i;
+            }
+            float4 pj[kAhead], vj[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) {
+                pj[u] = posType[js[u]];
+                vj[u] = velMass[js[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) {
+                if (!has[u]) continue;
+                const float xx = Sb.p.x - pj[u].x, xy = Sb.p.y - pj[u].y, xz = Sb.p.z - pj[u].z;
+                const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
+                wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, true, vj[u].w, vj[u].x, vj[u].y, vj[u].z);
+            }
+        }
+    }
+    return make_float4(Sb.fx, Sb.fy, Sb.fz, 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // density + pressure + hit record (scenes without TYPE_RIGID particles: only fluid neighbours count)
 // ------------------------------------------------------------------------------------------------
@@ -46,6 +90,7 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                                                             unsigned char *__restrict__ hitCount,
                                                             unsigned char *__restrict__ wallCount,
                                                             int *__restrict__ wallList,
+                                                            float4 *__restrict__ wallForce,
                                                             float *__restrict__ density,
                                                             float *__restrict__ pressure,
                                                             float2 *__restrict__ pd, int run_log) {
@@ -332,8 +377,15 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
         if (words > kHitExtra || wwords > kHitWall) words = kHitOverflow;
         if (words == kHitOverflow) wwords = 0;
     }
-    // particles with wall neighbours are listed for the wall pass (any order: they are independent)
-    {
+    // Wall neighbours.  wallList == nullptr: summed right here -- the wavefronts of a block go their own ways from
+    // now on, and one that holds particles at a wall simply ends later; else the particles are listed for a pass
+    // of their own (any order: they are independent).
+    if (!wallList) {
+        if (active && wwords > 0) {
+            const uint2 *wp = hitWords + (size_t)blk * kHitSlots * BS + (size_t)(kMaxSegs + kHitExtra) * BS + tid;
+            wallForce[index] = wall_sum<BS>(P, index, wp, wwords, posType, velMass);
+        }
+    } else {
         const bool listed = active && wwords > 0;
         const unsigned long long m = __ballot(listed);
         if (m) {
@@ -372,48 +424,10 @@ __global__ __launch_bounds__(256) void wall_force_kernel(DevParams<float> P, con
                                                          const unsigned char *__restrict__ wallCount,
                                                          float4 *__restrict__ wallForce) {
     const int count = wallList[0];
-    const float sr = P.sr, sr2 = sr * sr;
-    const float kspiky = P.kspikydiff, visc_eps = 0.01f * sr2;
-    const WallConsts W(P);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
         const int i = wallList[1 + e];
-        ForceSelf<float> Sb;
-        Sb.p = posType[i];
-        Sb.v = velMass[i];
-        Sb.pterm = 0.f;
-        Sb.fx = Sb.fy = Sb.fz = 0.f;
         const uint2 *wp = hitWords + (size_t)(i / BS) * kHitSlots * BS + (size_t)(kMaxSegs + kHitExtra) * BS + (i % BS);
-        const int words = wallCount[i];
-        for (int k = 0; k < words; k++) {
-            const uint2 w = wp[(size_t)k * BS];
-            unsigned m = w.x;
-            while (m) {  // four neighbours' loads in flight at a time; the sums stay in neighbour order
-                constexpr int kAhead = 4;
-                int js[kAhead];
-                bool has[kAhead];
-#pragma unroll
-                for (int u = 0; u < kAhead; u++) {
-                    has[u] = m != 0;
-                    const int b = __builtin_clz(m | 1u);
-                    if (has[u]) m &= ~(0x80000000u >> b);
-                    js[u] = has[u] ? (int)w.y + b : i;
-                }
-                float4 pj[kAhead], vj[kAhead];
-#pragma unroll
-                for (int u = 0; u < kAhead; u++) {
-                    pj[u] = posType[js[u]];
-                    vj[u] = velMass[js[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < kAhead; u++) {
-                    if (!has[u]) continue;
-                    const float xx = Sb.p.x - pj[u].x, xy = Sb.p.y - pj[u].y, xz = Sb.p.z - pj[u].z;
-                    const float d2 = __builtin_fmaf(xz, xz, __builtin_fmaf(xy, xy, xx * xx));
-                    wall_pair_fast(Sb, W, sr, kspiky, visc_eps, xx, xy, xz, d2, true, vj[u].w, vj[u].x, vj[u].y, vj[u].z);
-                }
-            }
-        }
-        wallForce[i] = make_float4(Sb.fx, Sb.fy, Sb.fz, 0.f);
+        wallForce[i] = wall_sum<BS>(P, i, wp, wallCount[i], posType, velMass);
     }
 }
 
@@ -655,6 +669,7 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+constexpr int kWallTailMax = 4 << 20;  // particles up to which the density pass sums the wall neighbours itself
 constexpr int kQueueD = 10;  // density queue: 4-byte slots (with the tile: 19.6 KB of LDS per workgroup)
 
 static inline int tiled_grid(const Solver *s, int run_log) {
@@ -664,14 +679,21 @@ static inline int tiled_grid(const Solver *s, int run_log) {
 
 template <bool EVAL> static int launch_density_record(Solver *s) {
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8);
-    if (!s->wall_list_clean)  // the list of the wall pass starts empty (the force pass leaves it so)
-        FSA_HIP(hipMemsetAsync(s->b.wallList, 0, sizeof(int), s->stream));
-    s->wall_list_clean = false;
+    // Where the wall neighbours are summed.  A pass of their own costs about 40 us whatever the size (a chain of
+    // dependent loads and a launch); in the tail of this pass they cost nothing fixed, but hold up the wavefronts
+    // that have them (16 M particles, disordered: +0.2 ms against +0.05).  Small solvers take the tail.
+    const bool in_tail = s->wall_mode == 0 ? s->n <= kWallTailMax : s->wall_mode == 1;  // (n: as last known on the host)
+    if (!in_tail) {
+        if (!s->wall_list_clean)  // the list of the wall pass starts empty (the force pass leaves it so)
+            FSA_HIP(hipMemsetAsync(s->b.wallList, 0, sizeof(int), s->stream));
+        s->wall_list_clean = false;
+    }
+    s->wall_listed = !in_tail;
     hipLaunchKernelGGL((density_record_kernel<kTunedBS, kRowCap, kQueueD, EVAL>), dim3(tiled_grid(s, s->xcd_run_log)),
                        dim3(kTunedBS), 0, s->stream, s->pf, s->grid_n(), (const float4 *)s->b.posType[c],
                        (const float4 *)s->b.velMass[c], (const float *)s->b.restDensity[c], s->b.cellStart,
-                       s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, s->b.wallCount, s->b.wallList,
-                       (float *)s->b.density, (float *)s->b.pressure, (float2 *)s->b.pd, run_log);
+                       s->b.sortedHash, (uint2 *)s->b.hitWords, s->b.hitCount, s->b.wallCount,
+                       in_tail ? nullptr : s->b.wallList, (float4 *)s->b.wallForce, (float *)s->b.density, (float *)s->b.pressure, (float2 *)s->b.pd, run_log);
     FSA_HIP(hipGetLastError());
     s->hits_valid = true;
     return FSA_OK;
@@ -696,7 +718,7 @@ int launch_force_fast(Solver *s) {
         if (rc) return rc;
     }
     const int c = s->cur, run_log = s->xcd_run_log | (s->dbg_fast << 8), zone = s->force_zone;
-    if (zone != 2) {  // (zone 2 follows zone 1, which has run it)
+    if (zone != 2 && s->wall_listed) {  // (zone 2 follows zone 1, which has run it)
         ScopedTimer t(s, "wall_force");
         hipLaunchKernelGGL((wall_force_kernel<kTunedBS>), dim3(1024), dim3(256), 0, s->stream, s->pf, s->b.wallList,
                            (const float4 *)s->b.posType[c], (const float4 *)s->b.velMass[c],

@@ -3,7 +3,7 @@
 * developed flow: the oracle runs a small dam break for 300 steps (the column has collapsed, the fluid lies against
   the walls and the floor, neighbourhoods are disordered); every stage of the HIP path is then compared with the
   oracle from THAT state, per element (tests/util.py);
-* BASELINE config 2 at its own size: one step of the 1 M-particle dam break against the oracle: hash, sorted order
+* the 1 M-particle single-GPU workload at its own size: one step of the 1 M-particle dam break against the oracle: hash, sorted order
   and cell ranges bit for bit, density / pressure / force within the per-element bars.
 """
 import numpy as np

@@ -113,3 +113,19 @@ def test_rank_in_very_crowded_cells(orc32):
     assert np.array_equal(b.get("uniqueId"), st["uniqueId"])
     assert np.array_equal(b.get("particleHash"), st["particleHash"])
     a.close(); b.close(); st.close()
+
+
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_wall_sum_placement_gives_the_same_bits(scene, monkeypatch):
+    """variant 3 sums a particle's wall neighbours either in the tail of the density pass or in a pass of their own
+    (by solver size; FSA_WALL_PASS, read at creation, forces one): same sums in the same order"""
+    sc = SCENES[scene]()
+    got = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FSA_WALL_PASS", mode)
+        _, s = gpu_solver(sc, 0)
+        s.set_variant(3)
+        s.step(6)
+        got.append(snapshot(s))
+        s.close()
+    same(got[0], got[1])
