@@ -249,8 +249,10 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                 group_d2<true>(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], pi.x, pi.y, pi.z, d2);
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    if (EVAL && !(dbg & 16)) q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
-                    if constexpr (!MASKED && EVAL) {
+                    // (the first and the last group of a range: candidates outside it are moved out of reach)
+                    if constexpr (MASKED && EVAL) d2[u] = (unsigned)(u - lo) < (unsigned)(hi - lo) ? d2[u] : kFar;
+                    if (EVAL) q[cnt * BS] = d2[u];  // a miss is overwritten by the next store
+                    if constexpr (EVAL && (MASKED || !MASKED)) {  // (a condition that depends on the lambda's own parameter)
                         // one compare, then the hit goes into the queue count and into the bit mask as a carry
                         unsigned long long carry_out;
                         asm("v_cmp_gt_f32 vcc, %[sr2], %[d2]\n\t"
