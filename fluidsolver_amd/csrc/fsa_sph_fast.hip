@@ -1,4 +1,4 @@
-// Fast fp32 density and force passes for gfx950 (kernel variant 2): one neighbour search per step.
+// Fast fp32 density and force passes for gfx950 (kernel variant 3): one neighbour search per step.
 //
 // The two passes of a WCSPH step look at the same positions, so the search runs once:
 //
@@ -6,9 +6,13 @@
 //            through double-buffered LDS tiles kept as separate x / y / z arrays (as in fsa_sph_tuned.hip);
 //            every lane walks its own index range of a row in aligned groups of four candidates, appends the
 //            squared distances of the hits to its LDS queue for the kernel evaluation, and also keeps ONE BIT
-//            per candidate in a register (one add-with-carry per candidate).  Every eight groups, and at the
-//            end of a row, the word goes to global memory as {mask, index of its first candidate} if it has a
-//            bit set: 8 bytes per 32 candidates.
+//            per candidate in a register (one add-with-carry per candidate).  At the end of a row the bits go to
+//            global memory: the row's main word (57 candidates from the lane's first group on, and that group's
+//            index), extra words for what a longer range holds beyond, and words of their own for the
+//            TYPE_BOUNDARY neighbours (layout: fsa_tile.h);
+//   walls  : a fluid particle at a wall has dozens of wall neighbours, the particles around it none.  They are
+//            summed one particle per lane, either in the tail of the density pass or in a pass of their own over
+//            the particles the density pass listed (launch_density_record says which, and why);
 //   force  : no search.  The rows stream through LDS again, this time with everything a pair needs
 //            ({x, y, z, m}, {v, p/rho^2}, viscosity term: 36 bytes per particle, coalesced loads), and every
 //            lane walks the set bits of its recorded words for the row at hand and reads its neighbours from
@@ -20,8 +24,9 @@
 // marked and walks the cells in the replay kernels with the same pair arithmetic in the same order.
 // Sums run in the reference's neighbour order (rows z, y; ascending index; TYPE_BOUNDARY neighbours of the
 // force pass summed apart), so a particle's result depends neither on the tile alignment nor on which
-// particles share its workgroup.  Arithmetic of the pairs: cubic_fast / force_pair_fast (hardware sqrt /
-// rsq / rcp, fused multiply-adds), about 1e-7 relative per pair term away from the exact flavour.
+// particles share its workgroup, and equals that of the searching kernels of variant 2 bit for bit.
+// Arithmetic of the pairs: cubic_fast / force_pair_fast / wall_pair_fast (hardware sqrt / rsq / rcp, fused
+// multiply-adds), about 1e-7 relative per pair term away from the exact flavour.
 #include <type_traits>
 
 #include "fsa_fast.h"
