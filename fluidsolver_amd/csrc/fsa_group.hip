@@ -186,9 +186,9 @@ static int setup_member(Group &g, Member &mb, Solver *s, int rank) {
     s->hash_valid = s->hash_ahead = false;
     s->pf.own_lo = s->pd.own_lo = mb.own[0];
     s->pf.own_hi = s->pd.own_hi = mb.own[1];
-    // the layers a particle can leave for a neighbour from in one step (it would have to cross more than two to
-    // get there from anywhere else; the pack flags that)
-    const int reach = g.halo + 2;
+    // the layers a particle can leave for a neighbour from in one step (from anywhere else it would have to cross
+    // a whole cell layer, two particle spacings, to get there; the pack flags that)
+    const int reach = g.halo + 1;
     int edge[4] = {0, 0, 0, 0};
     if (mb.has_left) { edge[0] = mb.own[0]; edge[1] = std::min(mb.own[0] + reach, mb.own[1]); }
     if (mb.has_right) { edge[2] = std::max(mb.own[1] - reach, mb.own[0]); edge[3] = mb.own[1]; }
@@ -516,8 +516,8 @@ int fsa_slab_group_sync(fsa_slab_group *hg, fsa_slab_group_stats *st) {
     }
     if (error)
         return fail(FSA_ERR_CAPACITY, "slab group: a count outgrew its buffer (bits %d: 1 solver capacity, 2 / 4 message to the "
-                                      "left / right, 8 / 16 message from the left / right, 32 a particle crossed more than two "
-                                      "cell layers in one step); the state is invalid", error);
+                                      "left / right, 8 / 16 message from the left / right, 32 a particle crossed a whole cell "
+                                      "layer in one step); the state is invalid", error);
     return FSA_OK;
 }
 

@@ -442,8 +442,8 @@ __global__ __launch_bounds__(kBlock) void slab_edge_send_kernel(
     }
 }
 
-// vars[kVarError] bit 5: a particle outside the edge layers ended up in a neighbour's layers (it crossed more than
-// two cell layers in one step); its record was not sent and the run is invalid.
+// vars[kVarError] bit 5: a particle outside the edge layers ended up in a neighbour's layers (it crossed a whole
+// cell layer in one step); its record was not sent and the run is invalid.
 template <bool ADVECT>
 __global__ __launch_bounds__(kBlock) void slab_keep_hash_kernel(
     DevParams<float> P, int bound, int all_owned, SlabRanges R, const int *__restrict__ sortedHash,

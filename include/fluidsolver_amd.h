@@ -405,8 +405,8 @@ int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
  * Messages are sized from the counts of three steps earlier plus head room (record_cap = the most records one
  * message may ever carry).  If a count outgrows its message or a solver's capacity, the excess is dropped,
  * flagged on the device, and fsa_slab_group_sync (or the next entry point used on the solver) returns
- * FSA_ERR_CAPACITY: the state is then invalid.  The same happens when a particle crosses more than two cell layers
- * in one step next to a cut (only the particles of the halo + 2 layers next to a cut are looked at for sending).
+ * FSA_ERR_CAPACITY: the state is then invalid.  The same happens when a particle crosses a whole cell layer
+ * in one step next to a cut (only the particles of the halo + 1 layers next to a cut are looked at for sending).
  */
 typedef struct fsa_slab_group fsa_slab_group;
 #define FSA_SLAB_GROUP_ID_BYTES 128
@@ -417,7 +417,7 @@ typedef struct fsa_slab_group_stats {
     long long lost;          /* particles that left every range they could go to (no neighbour holds their layer) */
     long long records_sent;  /* by this process's members, up to three steps ago */
     int error_bits;          /* 0, or what overflowed: 1 capacity, 2/4 message out left/right, 8/16 in left/right,
-                                32 a particle crossed more than two cell layers in one step */
+                                32 a particle crossed a whole cell layer in one step */
 } fsa_slab_group_stats;
 int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts /* world + 1 */, int halo,
                                 int record_cap, fsa_slab_group **out);

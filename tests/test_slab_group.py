@@ -178,7 +178,7 @@ def test_group_reports_a_particle_that_jumps_layers():
     g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
                              max(ss.record_cap for ss in ranks))
     g.step(2)  # the first pack (before any sort) sends everything through the edge pass; the second one does not
-    with pytest.raises(capi.FsaError, match="crossed more than two"):
+    with pytest.raises(capi.FsaError, match="crossed a whole cell layer"):
         g.sync()
     g.close()
     for ss in ranks:
