@@ -245,25 +245,29 @@ static int transport(Group &g, long long msg) {
             hipStream_t main = s->stream;
             if (mb.comm != main) FSA_HIP(hipStreamWaitEvent(mb.comm, mb.ev_pack[slot], 0));
             s->stream = mb.comm;  // (the timer brackets the stream the copies run on)
+            hipError_t err = hipSuccess;
+            auto keep = [&](hipError_t e) {
+                if (err == hipSuccess) err = e;
+            };
             {
                 ScopedTimer t(s, "exchange");
                 for (int d = 0; d < 2; d++) {
                     if (!mb.send[d]) continue;
                     Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
                     // the neighbour must be through with what it received in the step before
-                    if (msg > 0) (void)hipStreamWaitEvent(mb.comm, peer.ev_unpack[prev], 0);
+                    if (msg > 0) keep(hipStreamWaitEvent(mb.comm, peer.ev_unpack[prev], 0));
                     const size_t bytes = (size_t)(1 + mb.size_out[d]) * g.rb;
                     char *dst = peer.recv[1 - d];
                     if (peer.s->device == s->device)
-                        (void)hipMemcpyAsync(dst, mb.send[d], bytes, hipMemcpyDeviceToDevice, mb.comm);
+                        keep(hipMemcpyAsync(dst, mb.send[d], bytes, hipMemcpyDeviceToDevice, mb.comm));
                     else
-                        (void)hipMemcpyPeerAsync(dst, peer.s->device, mb.send[d], s->device, bytes, mb.comm);
-                    (void)hipEventRecord(mb.ev_sent[d], mb.comm);
+                        keep(hipMemcpyPeerAsync(dst, peer.s->device, mb.send[d], s->device, bytes, mb.comm));
+                    keep(hipEventRecord(mb.ev_sent[d], mb.comm));
                     peer.bound_in[1 - d] = mb.size_out[d];
                 }
             }
-            s->stream = main;
-            FSA_HIP(hipGetLastError());
+            s->stream = main;  // (before any return)
+            FSA_HIP(err);
         }
     } else {
         Member &mb = g.m[0];
