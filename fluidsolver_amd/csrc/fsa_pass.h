@@ -59,6 +59,13 @@ template <typename Policy, typename = void> struct deep_replay : std::false_type
 template <typename Policy> struct deep_replay<Policy, std::void_t<decltype(Policy::kDeepReplay)>>
     : std::bool_constant<Policy::kDeepReplay> {};
 
+// `static constexpr bool kRowReplay = true`: the list pass reads its neighbours from row tiles in LDS (filled with
+// coalesced loads of positions and Nb records) instead of gathering every one from global memory
+// (list_rows_kernel).  For policies whose `pair` reads nothing of the neighbour beyond Nb and the position.
+template <typename Policy, typename = void> struct row_replay : std::false_type {};
+template <typename Policy> struct row_replay<Policy, std::void_t<decltype(Policy::kRowReplay)>>
+    : std::bool_constant<Policy::kRowReplay> {};
+
 // One particle against its 27 cells in the reference's order, neighbours from global memory.
 template <typename T, typename Policy>
 __device__ __forceinline__ void generic_walk(const DevParams<T> &P, const PassArrays<T> &A, int index,
@@ -364,6 +371,195 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
     if (active) Policy::finish(A, P, index, S);
 }
 
+// The list flavour with the neighbours in LDS.  A gather of 16 bytes per lane costs the vector memory pipeline one
+// look-up per distinct cache line, some 25 per instruction here, and a list pass makes one or two per neighbour; a
+// tile read costs four LDS cycles.  So the nine neighbour rows of the block stream through LDS once more, this time
+// holding everything `pair` reads of a neighbour (position, type, the policy's Nb record; filled with coalesced
+// loads, double buffered), and every lane walks its list, which is in row order, taking its neighbours from the
+// tiles.  A lane's entries per row vary a lot, so a lane may lag one row behind (both tiles are in LDS): the loop of
+// row r runs until nobody has entries of row r - 1 left, then the tile of r + 1 replaces that of r - 1, and it goes
+// on until fewer than kRowQuorum lanes have entries of r left.  Same `pair` calls in the same order as
+// list_pass_kernel: same bits.  Blocks whose rows need the large tiles, blocks that are not staged and lanes whose
+// list overflowed take list_pass_kernel's way.
+constexpr int kRowQuorum = 40;
+template <typename Policy, int BS, int ROWCAP, int K>
+__global__ __launch_bounds__(BS) void list_rows_kernel(DevParams<float> P, int n, PassArrays<float> A,
+                                                       const int *__restrict__ cellStart,
+                                                       const unsigned short *__restrict__ list,
+                                                       const unsigned short *__restrict__ counts, int xcd_log) {
+    using Nb = typename Policy::Nb;
+    constexpr bool kPos = !pos_in_nb<Policy>::value;  // positions in a tile of their own
+    constexpr int kRegs = (ROWCAP + BS - 1) / BS;
+    __shared__ int rowStartG[16], rowLen[16];  // 9 used
+    __shared__ int stagedFlag;
+    __shared__ float4 tilePos[kPos ? 2 * ROWCAP : 1];
+    __shared__ Nb tileNb[2 * ROWCAP];
+    if (P.halt && *P.halt) return;  // see DevParams::halt
+    const int tid = threadIdx.x;
+    const int b0 = xcd_block(xcd_log) * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int index = b0 + tid;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool active = false;
+    if (index < n) {
+        pi = A.posType[index];
+        active = Policy::wants(unpack_int(pi.w));
+        if (!active) Policy::skip(A, P, index);
+    }
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
+    if (tid < 9) rowStartG[tid] = P.rows[(size_t)(b0 / BS) * kRowTableStride + tid];
+    else if (tid < 18) rowLen[tid - 9] = P.rows[(size_t)(b0 / BS) * kRowTableStride + tid];
+    else if (tid == 18) stagedFlag = P.rows[(size_t)(b0 / BS) * kRowTableStride + 18];
+    __syncthreads();
+    typename Policy::Self S;
+    if (active) Policy::init(A, P, index, S);
+    const int cls = stagedFlag;
+    if (cls == 0) {
+        if (active) {
+            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+            Policy::finish(A, P, index, S);
+        }
+        return;
+    }
+    int cnt = active ? (int)counts[index] : 0;
+    const bool overflow = cnt == kListOverflow;
+    if (overflow) cnt = 0;
+    const uint2 *const L = reinterpret_cast<const uint2 *>(list) + (size_t)(b0 / BS) * (K / 4) * BS + tid;
+    auto entries = [&](int s) { return s < cnt ? L[(size_t)(s / 4) * BS] : make_uint2(0u, 0u); };
+    auto one_pair = [&](const float4 &pj, const Nb &nb, int j) {
+        const int tj = unpack_int(pj.w);
+        if (Policy::reach(tj) != 0) {
+            const float xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+            const float d2 = xx * xx + xy * xy + xz * xz;
+            Policy::pair(A, P, S, j == index, tj, j, xx, xy, xz, d2, pj, nb);
+        }
+    };
+    if (cls == 2) {  // large tiles: gathers (entries carry 10 index bits)
+        constexpr int bits = idx_bits<kRowCapBig>();
+        constexpr unsigned mask = (1u << bits) - 1u;
+        for (int s = 0; wave_any(s < cnt); s += 4) {
+            const uint2 w = entries(s);
+            const unsigned e[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (s + u < cnt) {
+                    const int j = rowStartG[(e[u] >> bits) & 15u] + (int)(e[u] & mask);
+                    const Nb nb = Policy::load(A, j);
+                    float4 pj;
+                    if constexpr (kPos) pj = A.posType[j]; else pj = nb.pos();
+                    one_pair(pj, nb, j);
+                }
+        }
+    } else {
+        constexpr int bits = idx_bits<kRowCap>();
+        constexpr unsigned mask = (1u << bits) - 1u;
+        static_assert(ROWCAP >= kRowCap, "tile too small for the rows of a class-1 block");
+        struct Stage {
+            float4 p;
+            Nb nb;
+        };
+        Stage e[kRegs];
+        auto fetch = [&](int r) {
+            const int s0 = rowStartG[r], len = rowLen[r];
+            const int last = len > 0 ? len - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < kRegs; k++) {
+                const int j = s0 + min(tid + k * BS, last);
+                if constexpr (kPos) e[k].p = A.posType[j];
+                e[k].nb = Policy::load(A, j);
+            }
+        };
+        auto store = [&](int r) {
+            const int buf = (r & 1) * ROWCAP, len = rowLen[r];
+#pragma unroll
+            for (int k = 0; k < kRegs; k++) {
+                const int t = tid + k * BS;
+                if (t < len) {
+                    if constexpr (kPos) tilePos[buf + t] = e[k].p;
+                    tileNb[buf + t] = e[k].nb;
+                }
+            }
+        };
+        // the lane's entry stream: four entries per word, the next word in flight
+        int s = 0;               // entries taken so far
+        unsigned long long cur;  // the entries of the word at hand that are still to come, lowest first
+        uint2 nxt;
+        {
+            const uint2 w = entries(0);
+            cur = ((unsigned long long)w.y << 32) | w.x;
+            nxt = entries(4);
+        }
+        struct Taken {
+            bool has;
+            int j;
+            float4 pj;
+            Nb nb;
+        };
+        fetch(0);
+        store(0);
+        __syncthreads();
+        fetch(1);
+        for (int r = 0; r < 9; r++) {
+            // Takes the lane's next entry if it belongs to a row up to r and starts the tile reads.  `part` 0: until
+            // no lane of the wavefront has an entry of a row before r; 1: until fewer than kRowQuorum lanes have
+            // one of row r (the last row: none).
+            auto next = [&](Taken &T, int part) -> bool {
+                const unsigned ent = (unsigned)cur & 0xffffu;
+                const int row = (int)(ent >> bits);
+                const bool has = s < cnt && row <= r;
+                if (part == 0) {
+                    if (!wave_any(s < cnt && row < r)) return false;
+                } else {
+                    const unsigned long long busy = __ballot(has);
+                    if (busy == 0ull || (r + 1 < 9 && __popcll(busy) < kRowQuorum)) return false;
+                }
+                const int t = has ? (int)(ent & mask) : 0, at = has ? (row & 1) * ROWCAP + t : 0;
+                T.has = has;
+                T.j = rowStartG[has ? row : 0] + t;
+                T.nb = tileNb[at];
+                if constexpr (kPos) T.pj = tilePos[at];
+                if (has) {
+                    s++;
+                    cur >>= 16;
+                    if ((s & 3) == 0) {
+                        cur = ((unsigned long long)nxt.y << 32) | nxt.x;
+                        nxt = entries(s + 4);
+                    }
+                }
+                return true;
+            };
+            auto eval = [&](const Taken &T) {
+                if (!T.has) return;
+                float4 pj;
+                if constexpr (kPos) pj = T.pj; else pj = T.nb.pos();
+                one_pair(pj, T.nb, T.j);
+            };
+            // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated
+            auto run = [&](int part) {
+                Taken T0, T1;
+                bool go = next(T0, part);
+                while (go) {
+                    const bool go1 = next(T1, part);
+                    eval(T0);
+                    if (!go1) break;
+                    go = next(T0, part);
+                    eval(T1);
+                }
+            };
+            run(0);
+            if (r + 1 < 9) {
+                __syncthreads();  // everyone is done with the tile of row r - 1
+                store(r + 1);
+                if (r + 2 < 9) fetch(r + 2);
+            }
+            run(1);
+            if (r + 1 < 9) __syncthreads();  // the tile of row r + 1 is visible
+        }
+    }
+    if (overflow) generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+    if (active) Policy::finish(A, P, index, S);
+}
+
 static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 #define DF_DISPATCH(kernel, ...)                                                                                  \
@@ -419,10 +615,14 @@ static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F3
 template <typename Policy> static int run_tiled(Solver *s, const PassArrays<float> &A, bool lists) {
     const int unit = kXcds << s->xcd_run_log;
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-    if (lists && s->use_lists && s->lists_valid)
-        hipLaunchKernelGGL((list_pass_kernel<Policy, kTunedBS, kListSlots>), dim3(nb), dim3(kTunedBS), 0, s->stream,
-                           s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, s->xcd_run_log);
-    else
+    if (lists && s->use_lists && s->lists_valid) {
+        if constexpr (row_replay<Policy>::value)
+            hipLaunchKernelGGL((list_rows_kernel<Policy, kTunedBS, kRowCap, kListSlots>), dim3(nb), dim3(kTunedBS), 0,
+                               s->stream, s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, s->xcd_run_log);
+        else
+            hipLaunchKernelGGL((list_pass_kernel<Policy, kTunedBS, kListSlots>), dim3(nb), dim3(kTunedBS), 0, s->stream,
+                               s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, s->xcd_run_log);
+    } else
     {
         hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
                            s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, s->xcd_run_log);
