@@ -542,8 +542,11 @@ __global__ void slab_after_unpack_kernel(const char *__restrict__ recvLeft, cons
     vars[kVarLost] += counters[3];
     counters[3] = 0;
     if (mirror) {
-        mirror[4] = cl;
-        mirror[5] = cr;
+        // the counts as the neighbours sent them (cut to what the messages hold), not as the capacity let them in:
+        // the neighbours size their next messages from the same numbers, and both ends must arrive at the same size
+        const long long hl = recvLeft ? ((const long long *)recvLeft)[0] : 0, hr = recvRight ? ((const long long *)recvRight)[0] : 0;
+        mirror[4] = (int)(hl < 0 ? 0 : (hl > boundLeft ? boundLeft : hl));
+        mirror[5] = (int)(hr < 0 ? 0 : (hr > boundRight ? boundRight : hr));
         mirror[6] = at + cl + cr;
         mirror[7] = vars[kVarError];
     }
