@@ -199,3 +199,23 @@ def test_group_refuses_members_changed_between_steps():
     g.close()
     for ss in ranks:
         ss.close()
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_group_with_either_wall_sum_placement(mode, monkeypatch):
+    """large slab solvers sum the wall neighbours in a pass of their own, which the group step runs once before the
+    forces next to the cuts; small ones (all the test scenes) in the tail of the density pass.  Both forced here."""
+    monkeypatch.setenv("FSA_WALL_PASS", mode)
+    sc = SCENES["ddam"]()
+    ref = plain_gpu_run(sc, STEPS, 3)
+    ranks = make_ranks(sc, 3)
+    g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                             max(ss.record_cap for ss in ranks))
+    g.step(STEPS)
+    st = g.sync()
+    assert st.lost == 0 and st.error_bits == 0
+    uid, got = merged([ss.owned() for ss in ranks])
+    assert_same_bits(uid, got, ref)
+    g.close()
+    for ss in ranks:
+        ss.close()
