@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="dam16m"); ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--spinup", type=int, default=100)
 ap.add_argument("--dims", type=int, nargs=3, default=None, help="dam break of nx ny nz particles instead of --scene")
+ap.add_argument("--check", action="store_true", help="compare every owned particle with a plain single-solver run, bit for bit")
 ap.add_argument("--show", type=int, default=-1, help="slab whose kernel times are printed (default: the middle one)")
 a = ap.parse_args()
 if a.dims:
@@ -36,6 +37,24 @@ kt = ranks[show].backend.solver.timing_read()
 res["slab"] = show
 res["kernels_ms"] = {k: round(ms / c, 4) for k, (c, ms) in kt.items() if c}
 res["kernels_sum_ms"] = round(sum(ms / c for k, (c, ms) in kt.items() if c), 4)
+if a.check:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from test_slabs_cpu import assert_same_bits, merged
+    total = a.spinup + a.steps
+    # the group leaves the particles integrated; the plain run's results for the same instant
+    p = capi.make_params(capi.PRECISION_F32, **sc["params"])
+    ps = capi.Solver(p, len(sc["pos"]))
+    ps.upload(sc)
+    ps.step(total - 1)
+    ps.sort_particles(); ps.compute_pressure(); ps.compute_force()
+    ref = {k: ps.get(k) for k in ("density", "pressure", "force")}
+    ps.advect()
+    for k in ("pos", "vel", "uniqueId", "type"):
+        ref[k] = ps.get(k)
+    ps.close()
+    uid, got = merged([ss.owned() for ss in ranks])
+    assert_same_bits(uid, got, ref)
+    res["check"] = "every owned particle equals the plain run bit for bit"
 print(json.dumps(res))
 g.close()
 for ss in ranks:
