@@ -228,7 +228,12 @@ static int pack_edges(Group &g, Member &mb, long long msg, bool with_advect) {
     if (rc) return rc;
     const int slot = (int)(msg % kRing);
     rc = launch_slab_edge_send(s, with_advect, mb.own, mb.left, mb.right, mb.send[0], mb.size_out[0], mb.send[1],
-                               mb.size_out[1], mb.mirror + slot * kMirrorInts);
+                               mb.size_out[1]);
+    if (rc) return rc;
+    // (the headers on the solver's stream too: a kernel on the transport's stream was tried and, with several
+    // members per GPU, costs more in stream switching than the launch it takes off this one)
+    rc = launch_slab_pack_tail(s, s->stream, mb.send[0], mb.size_out[0], mb.send[1], mb.size_out[1],
+                               mb.mirror + slot * kMirrorInts);
     if (rc) return rc;
     FSA_HIP(hipEventRecord(mb.ev_pack[slot], s->stream));
     s->count_stale = true;

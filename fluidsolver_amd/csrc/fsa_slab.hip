@@ -19,6 +19,8 @@
 // Slab groups (fsa_group.hip) run the same exchange without moving the particles that stay: one pass integrates,
 // classifies, writes the records and computes the next step's hash (dropped slots are marked, not compacted away),
 // a second appends the received records with their hash, and the sort that follows gathers what is left.
+#include <algorithm>
+
 #include "fsa_advect.h"
 #include "fsa_hash.h"
 #include "fsa_solver.h"
@@ -287,10 +289,10 @@ __global__ __launch_bounds__(kBlock) void slab_init_keys_kernel(int n, const int
 // ---- exchange without host round trips (slab groups, fsa_group.hip) --------------------------------------------
 // (slabVars[]: fsa_solver.h)
 
-// After slab_edge_send_kernel: the counts leave the atomic counters (which go back to zero for the next
-// pack), each send buffer gets its count into its header slot, and a copy goes to `mirror` (pinned host memory) for
-// the host to read some steps later.  Counts beyond what the messages take are cut and flagged in
-// slabVars[kVarError]: bits 1 / 2 send buffer left / right.  The particle count stays: nothing has been moved.
+// After slab_edge_send_kernel: the counts leave the atomic counters (which go back to zero for the next pack), each
+// send buffer gets its count into its header slot, and a copy goes to `mirror` (pinned host memory) for the host to
+// read some steps later.  Counts beyond what the messages take are cut and flagged in slabVars[kVarError]: bits
+// 1 / 2 send buffer left / right.  The particle count stays: nothing has been moved.
 __global__ void slab_after_pack_kernel(int *__restrict__ counters, int *__restrict__ vars, int sizeLeft,
                                        int sizeRight, long long *__restrict__ hdrLeft,
                                        long long *__restrict__ hdrRight, int *__restrict__ mirror) {
@@ -300,17 +302,16 @@ __global__ void slab_after_pack_kernel(int *__restrict__ counters, int *__restri
     if (r > sizeRight) { r = sizeRight; err |= 4; }
     vars[kVarOutLeft] = l;
     vars[kVarOutRight] = r;
-    vars[kVarLost] += counters[3];
-    vars[kVarError] |= err;
+    if (err) atomicOr(vars + kVarError, err);  // (the keep pass may be flagging on another stream)
     if (hdrLeft) hdrLeft[0] = l;
     if (hdrRight) hdrRight[0] = r;
     if (mirror) {
         mirror[0] = l;
         mirror[1] = r;
         mirror[2] = vars[kVarN];
-        mirror[3] = vars[kVarError];
+        mirror[3] = err;
     }
-    counters[0] = counters[1] = counters[2] = counters[3] = 0;
+    counters[1] = counters[2] = 0;
 }
 
 // The counts of the two receive buffers as the unpack uses them (cut to what the message and the capacity take).
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void slab_keep_hash_kernel(
             }
             bool lost;
             flags = classify(P, R, p, lost);
-            if (lost) atomicAdd(counters + 3, 1);
+            if (lost) atomicAdd(vars + kVarLost, 1);
             if (!edge && (flags & 6u)) atomicOr(vars + kVarError, 32);
         }
     }
@@ -485,14 +486,32 @@ __global__ __launch_bounds__(kBlock) void slab_keep_hash_kernel(
 // their hash and arrival slots (they lie in the layers this solver holds: the sender selected them by that).
 __global__ __launch_bounds__(kBlock) void slab_unpack_hash_kernel(
     DevParams<float> P, const char *__restrict__ recvLeft, const char *__restrict__ recvRight, int boundLeft,
-    int boundRight, const int *__restrict__ vars, int capacity, float4 *__restrict__ posType,
+    int boundRight, int *__restrict__ vars, int capacity, float4 *__restrict__ posType,
     float4 *__restrict__ velMass, float *__restrict__ restDensity, int *__restrict__ uniqueId,
     long long *__restrict__ key, int *__restrict__ hash, int *__restrict__ slot, int *__restrict__ cellCount,
-    int *__restrict__ undefBlockCount, int *__restrict__ counters) {
-    const int at = vars[kVarN];
+    int *__restrict__ undefBlockCount, int *__restrict__ mirror) {
+    const int at = vars[kVarN];  // (not written by this kernel)
     int cl, cr, err;
     incoming_counts((const long long *)recvLeft, (const long long *)recvRight, boundLeft, boundRight, at, capacity, cl,
                     cr, err);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the number of slots after the append (what the sort reads), the counts, and their mirror for the host
+        vars[kVarSlots] = at + cl + cr;
+        vars[kVarInLeft] = cl;
+        vars[kVarInRight] = cr;
+        if (err) atomicOr(vars + kVarError, err);
+        if (mirror) {
+            // the counts as the neighbours sent them (cut to what the messages hold), not as the capacity let them
+            // in: the neighbours size their next messages from the same numbers, and both ends must arrive at the
+            // same size
+            const long long hl = recvLeft ? ((const long long *)recvLeft)[0] : 0,
+                            hr = recvRight ? ((const long long *)recvRight)[0] : 0;
+            mirror[4] = (int)(hl < 0 ? 0 : (hl > boundLeft ? boundLeft : hl));
+            mirror[5] = (int)(hr < 0 ? 0 : (hr > boundRight ? boundRight : hr));
+            mirror[6] = at + cl + cr;
+            mirror[7] = err;
+        }
+    }
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if ((int)blockIdx.x * kBlock >= cl + cr) return;
     const bool valid = k < cl + cr;
@@ -514,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void slab_unpack_hash_kernel(
         }
         if (h == FSA_GRID_UNDEF || h == kHashDrop) {  // not in the layers held here: nobody should have sent it
             h = kHashDrop;
-            atomicAdd(counters + 3, 1);
+            atomicAdd(vars + kVarLost, 1);
         }
         // out-of-grid ranks are kept per block of kBlock slots; the blocks that begin in the appended part have none
         if (i % kBlock == 0) undefBlockCount[i / kBlock] = 0;
@@ -523,32 +542,6 @@ __global__ __launch_bounds__(kBlock) void slab_unpack_hash_kernel(
     if (valid) {
         hash[i] = (int)h;
         slot[i] = my;
-    }
-}
-
-// The number of slots after the append (what the sort reads), the counts, and their mirror for the host.
-__global__ void slab_after_unpack_kernel(const char *__restrict__ recvLeft, const char *__restrict__ recvRight,
-                                         int boundLeft, int boundRight, int *__restrict__ vars, int capacity,
-                                         int *__restrict__ counters, int *__restrict__ mirror) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int at = vars[kVarN];
-    int cl, cr, err;
-    incoming_counts((const long long *)recvLeft, (const long long *)recvRight, boundLeft, boundRight, at, capacity, cl,
-                    cr, err);
-    vars[kVarSlots] = at + cl + cr;
-    vars[kVarInLeft] = cl;
-    vars[kVarInRight] = cr;
-    vars[kVarError] |= err;
-    vars[kVarLost] += counters[3];
-    counters[3] = 0;
-    if (mirror) {
-        // the counts as the neighbours sent them (cut to what the messages hold), not as the capacity let them in:
-        // the neighbours size their next messages from the same numbers, and both ends must arrive at the same size
-        const long long hl = recvLeft ? ((const long long *)recvLeft)[0] : 0, hr = recvRight ? ((const long long *)recvRight)[0] : 0;
-        mirror[4] = (int)(hl < 0 ? 0 : (hl > boundLeft ? boundLeft : hl));
-        mirror[5] = (int)(hr < 0 ? 0 : (hr > boundRight ? boundRight : hr));
-        mirror[6] = at + cl + cr;
-        mirror[7] = vars[kVarError];
     }
 }
 
@@ -660,7 +653,7 @@ int launch_slab_unpack(Solver *s, const void *recs, int count) {
 // headers.  sendLeft / sendRight are whole send buffers (header slot first); sizeLeft / sizeRight the records this
 // step's messages take.  with_advect: the integration of the step before runs in the same passes.
 int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const int left[2], const int right[2],
-                          void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror) {
+                          void *sendLeft, int sizeLeft, void *sendRight, int sizeRight) {
     const int rb = slab_record_bytes(s), c = s->cur, n = s->grid_n();
     ScopedTimer t(s, "edge_send");
     SlabRanges R{own[0], own[1], s->pf.z0, s->pf.z0 + s->pf.nz, left[0], left[1], right[0], right[1]};
@@ -676,8 +669,16 @@ int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const i
         if (with_advect) FSA_ES(true); else FSA_ES(false);
     }
 #undef FSA_ES
-    hipLaunchKernelGGL(slab_after_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->b.slabCounters, s->b.slabVars,
-                       l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// The message headers of the edge pass, on `stream` (where it must follow the edge pass).
+int launch_slab_pack_tail(Solver *s, void *stream, void *sendLeft, int sizeLeft, void *sendRight, int sizeRight,
+                          int *mirror) {
+    char *l = (char *)sendLeft, *r = (char *)sendRight;
+    hipLaunchKernelGGL(slab_after_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s->b.slabCounters,
+                       s->b.slabVars, l ? sizeLeft : 0, r ? sizeRight : 0, (long long *)l, (long long *)r, mirror);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
@@ -711,15 +712,12 @@ int launch_slab_unpack_hash(Solver *s, const void *recvLeft, int boundLeft, cons
                             int *mirror) {
     ScopedTimer t(s, "unpack_hash");
     const int c = s->cur, bound = (recvLeft ? boundLeft : 0) + (recvRight ? boundRight : 0);
-    if (bound > 0)
-        hipLaunchKernelGGL(slab_unpack_hash_kernel, dim3(blocks_for(bound)), dim3(kBlock), 0, s->stream, s->pf,
-                           (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
-                           s->capacity, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
-                           (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c], s->b.hash, s->b.slot,
-                           s->b.cellCount, s->b.undefBlockCount, s->b.slabCounters);
-    hipLaunchKernelGGL(slab_after_unpack_kernel, dim3(1), dim3(64), 0, s->stream, (const char *)recvLeft,
-                       (const char *)recvRight, boundLeft, boundRight, s->b.slabVars, s->capacity, s->b.slabCounters,
-                       mirror);
+    // (at least one block: its first thread also publishes the counts)
+    hipLaunchKernelGGL(slab_unpack_hash_kernel, dim3(std::max(blocks_for(bound), 1)), dim3(kBlock), 0, s->stream, s->pf,
+                       (const char *)recvLeft, (const char *)recvRight, boundLeft, boundRight, s->b.slabVars,
+                       s->capacity, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
+                       (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c], s->b.hash, s->b.slot,
+                       s->b.cellCount, s->b.undefBlockCount, mirror);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }

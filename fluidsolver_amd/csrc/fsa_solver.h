@@ -228,7 +228,9 @@ int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int l
                      void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
 int launch_slab_unpack(Solver *s, const void *recs, int count);
 int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const int left[2], const int right[2],
-                          void *sendLeft, int sizeLeft, void *sendRight, int sizeRight, int *mirror);
+                          void *sendLeft, int sizeLeft, void *sendRight, int sizeRight);
+int launch_slab_pack_tail(Solver *s, void *stream, void *sendLeft, int sizeLeft, void *sendRight, int sizeRight,
+                          int *mirror);
 int launch_slab_keep_hash(Solver *s, bool with_advect, const int own[2], const int keep[2], const int left[2],
                           const int right[2]);
 int launch_slab_unpack_hash(Solver *s, const void *recvLeft, int boundLeft, const void *recvRight, int boundRight,
