@@ -1094,10 +1094,12 @@ int fsa_iisph_solve_pressure(fsa_solver *hs, int maxiter, int *rounds, double *l
     TRY(launch_iisph_rounds_begin(s));
     int rc = FSA_OK;
     for (int iter = 0; iter < maxiter && !rc; iter++) {
+        s->iisph_chain = iter == 0 ? 1 : 2;  // the passes hand their packed records on to each other
         rc = fsa_iisph_calc_dijpjl(hs);
         if (!rc) rc = fsa_iisph_calc_new_pressure(hs);
         if (!rc) rc = launch_iisph_round_end(s);
     }
+    s->iisph_chain = 0;
     int done = 0;
     double mean = 0.0;
     const int rc2 = launch_iisph_rounds_finish(s, maxiter, &done, &mean);

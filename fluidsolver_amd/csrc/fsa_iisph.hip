@@ -586,7 +586,14 @@ struct IisphDijpjlFastPolicy {
     }
     static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
         const T k = -(S.mass * P.dt * P.dt);
-        A.dijpjl[index] = Vec3<T>{S.ax * k, S.ay * k, S.az * k};
+        const Vec3<T> d{S.ax * k, S.ay * k, S.az * k};
+        A.dijpjl[index] = d;
+        if (A.recOut) {  // what CalcNewPressure reads of this particle (as iisph_pack_cvec_kernel writes it)
+            const Vec3<T> a = A.dii[index];
+            const T p = A.pressure[index];
+            A.recOut[index] = make_float4(__builtin_fmaf(a.x, p, d.x), __builtin_fmaf(a.y, p, d.y),
+                                          __builtin_fmaf(a.z, p, d.z), A.restDensity[index]);
+        }
     }
 };
 
@@ -595,7 +602,7 @@ struct IisphNewPressureFastPolicy {
     static constexpr bool kDeepReplay = true;
     static constexpr bool kRowReplay = true;  // two gathers per neighbour otherwise: 1.96 -> 1.77 ms from the row tiles
     static __device__ __forceinline__ int reach(int tj) { return iisph_reach(tj); }
-    struct Self { T lll, p_i, mass, rd, k1, inv_h; Vec3<T> dijpjl; };
+    struct Self { T lll, p_i, mass, rd, k1, inv_h, dens; Vec3<T> dijpjl; };
     struct Nb { Vec4<T> c; };
     static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID; }
     static __device__ __forceinline__ void skip(const PassArrays<T> &A, const DevParams<T> &, int index) {
@@ -606,13 +613,14 @@ struct IisphNewPressureFastPolicy {
         S.lll = 0;
         S.p_i = A.pressure[index];
         const T dens = A.density[index];
+        S.dens = dens;
         S.mass = A.velMass[index].w;
         S.rd = A.restDensity[index];
         S.dijpjl = A.dijpjl[index];
         S.k1 = S.mass * P.dt * P.dt / (dens * dens) * S.p_i;  // d_ji p_i = gradW * k1 for a fluid neighbour
         S.inv_h = 2.0f / P.sr;
     }
-    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.aux4[j]}; }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.aux4b[j]}; }
     static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool, int tj,
                                                 int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
         if (d2 >= P.sr * P.sr) return;
@@ -640,6 +648,10 @@ struct IisphNewPressureFastPolicy {
         A.pressureOut[index] = np;
         density_corr += prev * aii;
         A.errorOut[index] = density_corr;
+        if (A.recOut) {  // what CalcDIJPJL reads of this particle in the next round (as iisph_pack_pterm_kernel writes it)
+            const Vec4<T> p = A.posType[index];
+            A.recOut[index] = make_float4(p.x, p.y, p.z, fluid_like(unpack_int(p.w)) ? np / S.dens / S.dens : 0.0f);
+        }
     }
 };
 
@@ -701,17 +713,40 @@ int launch_iisph_predict_density(Solver *s) {
     }
     IISPH_PASS(IisphPredictPolicy, "iisph_predict");
 }
+// The two passes of a pressure round in the fast flavour read one packed record per neighbour:
+//   CalcDIJPJL       {x, y, z, p / rho^2}                   in aux4
+//   CalcNewPressure  {d_jj p_j + dijpjl_j, restDensity_j}   in the second record buffer
+// Called on their own they pack the record first.  Inside fsa_iisph_solve_pressure (Solver::iisph_chain) each pass
+// writes, for its own particle, the record the next pass reads, so the two packing kernels run once per solve
+// instead of once per round (the particles the passes skip keep the records of that first packing: nothing about
+// them changes during the rounds).
+static void *second_records(Solver *s) { return s->b.hitWords; }  // (the WCSPH hit record is idle in this step)
+
 int launch_iisph_dijpjl(Solver *s) {
     if (s->n == 0) return FSA_OK;
     if (use_fast(s)) {
-        {
+        if (s->iisph_chain != 2) {
             ScopedTimer t(s, "iisph_pack_pterm");
             hipLaunchKernelGGL(iisph_pack_pterm_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
                                (const float4 *)s->b.posType[s->cur], (const float *)s->b.pressure,
                                (const float *)s->b.density, (float4 *)s->b.aux4);
             FSA_HIP(hipGetLastError());
         }
-        return launch_tuned<IisphDijpjlFastPolicy>(s, "iisph_dijpjl", true);
+        const int rc = ensure_lists(s);
+        if (rc) return rc;
+        ScopedTimer t(s, "iisph_dijpjl");
+        PassArrays<float> A = arrays_of<float>(s);
+        if (s->iisph_chain) {
+            if (s->iisph_chain == 1) {  // first round: the records of the particles the pass skips
+                s->hits_valid = false;
+                hipLaunchKernelGGL(iisph_pack_cvec_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                                   (const Vec3<float> *)s->b.dii, (const Vec3<float> *)s->b.dijpjl,
+                                   (const float *)s->b.pressure, (const float *)s->b.restDensity[s->cur],
+                                   (float4 *)second_records(s));
+            }
+            A.recOut = (float4 *)second_records(s);
+        }
+        return run_tiled<IisphDijpjlFastPolicy>(s, A, true);
     }
     IISPH_PASS(IisphDijpjlPolicy, "iisph_dijpjl");
 }
@@ -741,12 +776,18 @@ int launch_iisph_new_pressure(Solver *s) {
         ScopedTimer t(s, "iisph_new_pressure");
         int rc = FSA_OK;
         if (use_fast(s)) {
-            hipLaunchKernelGGL(iisph_pack_cvec_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
-                               (const Vec3<float> *)s->b.dii, (const Vec3<float> *)s->b.dijpjl,
-                               (const float *)s->b.pressure, (const float *)s->b.restDensity[s->cur],
-                               (float4 *)s->b.aux4);
             PassArrays<float> A = arrays_of<float>(s);
             A.pressureOut = (float *)s->b.pressure_alt;
+            if (s->iisph_chain) {  // the dijpjl pass before has written the records; this one writes the next round's
+                A.aux4b = (const float4 *)second_records(s);
+                A.recOut = (float4 *)s->b.aux4;
+            } else {
+                hipLaunchKernelGGL(iisph_pack_cvec_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                                   (const Vec3<float> *)s->b.dii, (const Vec3<float> *)s->b.dijpjl,
+                                   (const float *)s->b.pressure, (const float *)s->b.restDensity[s->cur],
+                                   (float4 *)s->b.aux4);
+                A.aux4b = (const float4 *)s->b.aux4;
+            }
             rc = run_tiled<IisphNewPressureFastPolicy>(s, A, true);
         } else if (use_tiles(s)) {
             PassArrays<float> A = arrays_of<float>(s);

@@ -27,6 +27,8 @@ template <typename T> struct PassArrays {
     const T *pstiffIn;
     const Vec3<T> *vStarIn;
     const Vec4<T> *aux4;  // {v_star, mass} per particle (tuned density-change passes)
+    const Vec4<T> *aux4b; // a second packed record per particle (IISPH pressure rounds)
+    Vec4<T> *recOut;      // where a pass writes the record the NEXT pass reads of this particle (null: nowhere)
     const T *aux2;        // {pstiff / density, mass} pairs (tuned applyPStiff)
     T *densityOut;
     T *dfFactorOut;

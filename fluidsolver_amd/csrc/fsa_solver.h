@@ -123,6 +123,7 @@ struct Solver {
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
+    int iisph_chain = 0;        // inside fsa_iisph_solve_pressure: 1 first round, 2 later rounds (fsa_iisph.hip)
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
     int force_zone = 0;  // variant-3 force pass: 0 all blocks, 1 only those that touch an edge (DevParams::edge), 2 the rest

@@ -277,3 +277,22 @@ def test_effective_mass_from_volume_fractions(prec, orc32, orc64):
     assert s.get("mass").tobytes() == st["mass"].tobytes()
     s.close()
     st.close()
+
+
+def test_pressure_solve_equals_the_stage_calls_round_by_round(pair):
+    """fsa_iisph_solve_pressure lets the two passes of a round hand their packed neighbour records on to each other
+    (the packing kernels run once per solve); the stage calls pack before every pass.  Same bits."""
+    sc, p, st, s, tol, variant = pair
+    setup_both(p, st, s)
+    s.non_pressure_force_multiphase()
+    s.iisph_predict_density()
+    start = {k: s.get(k) for k in ("pressure", "dijpjl", "error")}
+    rounds, _ = s.iisph_solve_pressure(4)
+    solved = {k: s.get(k) for k in ("pressure", "dijpjl", "error")}
+    for k, v in start.items():
+        s.set(k, v)
+    for _ in range(rounds):
+        s.iisph_calc_dijpjl()
+        s.iisph_calc_new_pressure()
+    for k in solved:
+        assert np.array_equal(s.get(k), solved[k], equal_nan=True), k
