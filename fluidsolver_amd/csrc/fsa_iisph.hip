@@ -173,6 +173,120 @@ template <typename T> struct NpfMultiPolicy {
     }
 };
 
+// Fast fp32 flavour of the same pass (kernel variants 2 and 3): hardware reciprocal square root / reciprocal, fused
+// multiply-adds, no double arithmetic per pair (about 1e-6 relative away from the exact flavour per term), and two
+// packed 16-byte records per neighbour, side by side, instead of four gathers:
+//   {x, y, z, type | group << 8}   {vx, vy, vz, mass / density}
+__global__ __launch_bounds__(kBlock) void iisph_pack_npf_kernel(int n, const float4 *__restrict__ posType,
+                                                                const float4 *__restrict__ velMass,
+                                                                const float *__restrict__ density,
+                                                                const int *__restrict__ groupSorted,
+                                                                float4 *__restrict__ rec) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = posType[i], v = velMass[i];
+    rec[2 * (size_t)i] = make_float4(p.x, p.y, p.z, __int_as_float(unpack_int(p.w) | (groupSorted[i] << 8)));
+    rec[2 * (size_t)i + 1] = make_float4(v.x, v.y, v.z, v.w / density[i]);
+}
+
+struct NpfMultiFastPolicy {
+    using T = float;
+    static constexpr bool kPosInNb = true;
+    static constexpr bool kDeepReplay = true;  // (the row tiles are no faster here: 2.15 against 2.22 ms)
+    static __device__ __forceinline__ int reach(int) { return 1; }  // surface tension couples any two types
+    struct Self {
+        float4 v;  // velocity, mass
+        float fx, fy, fz, dens, rd;
+        int type, group;
+        float h, inv_h, support, fac, sr6, visc_dt, half_dt, tension;
+    };
+    struct Nb {
+        float4 a, b;
+        __device__ __forceinline__ float4 pos() const {
+            return make_float4(a.x, a.y, a.z, __int_as_float(__float_as_int(a.w) & 255));
+        }
+    };
+    static __device__ __forceinline__ bool wants(int type) { return type != FSA_TYPE_RIGID && type != FSA_TYPE_CLOTH; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &A, const DevParams<T> &P, int index) {
+        NpfMultiPolicy<float>::skip(A, P, index);
+    }
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        S.v = A.velMass[index];
+        S.fx = S.fy = S.fz = 0;
+        S.dens = A.density[index];
+        S.rd = A.restDensity[index];
+        S.type = unpack_int(A.posType[index].w);
+        S.group = A.groupSorted[index];
+        S.h = (float)((double)P.sr * 0.5);
+        S.inv_h = 1.0f / S.h;
+        S.support = S.h * 2;
+        S.fac = (float)(32.0f / 3.141593 / pow((double)S.support, 9.0));
+        S.sr6 = (float)(pow((double)P.sr, 6.0) / 64.0);
+        S.visc_dt = P.viscosity / P.dt;
+        S.half_dt = 0.5f / P.dt;
+        S.tension = S.group == 4 ? P.surface_tension * 10 : P.surface_tension;
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) {
+        const float4 *r = A.aux4b + 2 * (size_t)j;
+        return Nb{r[0], r[1]};
+    }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &A, const DevParams<T> &P, Self &S, bool, int tj,
+                                                int j, T xx, T xy, T xz, T d2, const float4 &, const Nb &nb) {
+        if (d2 >= S.support * S.support || d2 < 1e-10f) return;  // (leaves the particle itself out)
+        const float rinv = __builtin_amdgcn_rsqf(d2), d = d2 * rinv;
+        const int gj = __float_as_int(nb.a.w) >> 8;
+        const float vx = S.v.x - nb.b.x, vy = S.v.y - nb.b.y, vz = S.v.z - nb.b.z;
+        const float volj = nb.b.w;
+        if (S.type == FSA_TYPE_FLUID && tj == FSA_TYPE_FLUID) {  // xsph artificial viscosity
+            const float w = cubic_fast(d2, S.inv_h, P.kernel_cubic);
+            const float c = -((S.group == 0 || gj == 0) ? S.visc_dt : S.half_dt) * volj * w;
+            S.fx = __builtin_fmaf(vx, c, S.fx);
+            S.fy = __builtin_fmaf(vy, c, S.fy);
+            S.fz = __builtin_fmaf(vz, c, S.fz);
+        }
+        if (S.group == gj) {  // surface tension
+            const float c = S.support - d, c3 = c * c * c, d3 = d * d2;
+            const float sf = d < S.h ? __builtin_fmaf(2.0f * c3, d3, -S.sr6) : c3 * d3;  // (d < support here)
+            const float k = -(S.tension * volj) * (sf * S.fac) * rinv;
+            S.fx = __builtin_fmaf(xx, k, S.fx);
+            S.fy = __builtin_fmaf(xy, k, S.fy);
+            S.fz = __builtin_fmaf(xz, k, S.fz);
+        }
+        if (tj == FSA_TYPE_RIGID && gj == 0) {  // wall viscosity and friction
+            const float xv = __builtin_fmaf(vz, xz, __builtin_fmaf(vy, xy, vx * xx));
+            if (xv < 0) {
+                const float gs = grad_scale_fast(d2, S.inv_h, P.kernel_cubic_gradient);
+                const float gx = xx * gs, gy = xy * gs, gz = xz * gs;
+                const Vec3<float> nj = A.normalById[A.uniqueId[j]];
+                const float rd_j = A.restDensity[j];
+                const float ndv = __builtin_fmaf(nj.z, vz, __builtin_fmaf(nj.y, vy, nj.x * vx));
+                const float tx = vx - nj.x * ndv, ty = vy - nj.y * ndv, tz = vz - nj.z * ndv;
+                const float visc = P.boundary_visc * P.sr * 88.5f * 0.25f * __builtin_amdgcn_rcpf(S.dens);
+                const float pi = visc * xv * __builtin_amdgcn_rcpf(__builtin_fmaf(0.01f, S.h * S.h, d2));
+                const float m = pi * S.rd * rd_j;
+                const float f0 = gx * m, f1 = gy * m, f2 = gz * m;
+                const float fdn = __builtin_fmaf(f2, nj.z, __builtin_fmaf(f1, nj.y, f0 * nj.x));
+                const float nx = nj.x * fdn, ny = nj.y * fdn, nz = nj.z * fdn;
+                const float k = -__builtin_amdgcn_sqrtf(__builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx))) *
+                                P.boundary_friction;
+                S.fx += nx;
+                S.fy += ny;
+                S.fz += nz;
+                S.fx = __builtin_fmaf(tx, k, S.fx);
+                S.fy = __builtin_fmaf(ty, k, S.fy);
+                S.fz = __builtin_fmaf(tz, k, S.fz);
+            }
+        }
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        Vec3<float> vs;
+        vs.x = __builtin_fmaf(S.fx + P.gravity[0], P.dt, S.v.x);
+        vs.y = __builtin_fmaf(S.fy + P.gravity[1], P.dt, S.v.y);
+        vs.z = __builtin_fmaf(S.fz + P.gravity[2], P.dt, S.v.z);
+        A.vStarOut[index] = vs;
+    }
+};
+
 // ---- IISPHFactorCell :3665-3715 + IISPHFactorKernel :3717-3749 ----------------------------------------
 // FAST (fp32, variant 2): hardware square root / reciprocal square root and fused multiply-adds, no double
 // arithmetic per pair; about 1e-6 relative away from the exact flavour per term
@@ -696,7 +810,21 @@ int launch_effective_mass(Solver *s) {
     return FSA_OK;
 }
 
-int launch_npf_multiphase(Solver *s) { IISPH_PASS(NpfMultiPolicy, "npf_multiphase"); }
+int launch_npf_multiphase(Solver *s) {
+    if (s->n > 0 && use_fast(s)) {
+        const int rc = ensure_lists(s);
+        if (rc) return rc;
+        ScopedTimer t(s, "npf_multiphase");
+        s->hits_valid = false;  // the records live in the buffer of the WCSPH hit record, which this step does not use
+        hipLaunchKernelGGL(iisph_pack_npf_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                           (const float4 *)s->b.posType[s->cur], (const float4 *)s->b.velMass[s->cur],
+                           (const float *)s->b.density, s->b.groupSorted, (float4 *)s->b.hitWords);
+        PassArrays<float> A = arrays_of<float>(s);
+        A.aux4b = (const float4 *)s->b.hitWords;
+        return run_tiled<NpfMultiFastPolicy>(s, A, true);
+    }
+    IISPH_PASS(NpfMultiPolicy, "npf_multiphase");
+}
 int launch_iisph_factor(Solver *s) {
     if (s->n > 0 && use_fast(s)) return launch_tuned<IisphFactorPolicy<float, true>>(s, "iisph_factor", true);
     IISPH_PASS(IisphFactorPolicy, "iisph_factor");
