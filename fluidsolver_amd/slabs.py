@@ -592,11 +592,33 @@ def _bench_distributed(args, build_scene):
     from . import capi
 
     def make_group():
-        uid = [capi.SlabGroup.unique_id() if rank == 0 else None]
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [capi.SlabGroup.unique_id()]
+            except Exception as exc:  # noqa: BLE001  (the other ranks wait in the broadcast: tell them)
+                print(f"rank 0: no RCCL unique id ({exc})", file=sys.stderr)
         dist.broadcast_object_list(uid, src=0)
+        if uid[0] is None:
+            raise RuntimeError("rank 0 could not make an RCCL unique id")
         return capi.SlabGroup.rccl(ss.backend.solver, rank, world, uid[0], ss.layout.cuts, ss.halo, ss.record_cap)
 
-    group = make_group() if native else None
+    group = None
+    if native:
+        # if any rank cannot make its communicator, all ranks agree on the torch transport and the bench line says so
+        try:
+            group = make_group()
+        except Exception as exc:  # noqa: BLE001
+            print(f"rank {rank}: the library's slab group could not be made ({exc}); using the torch transport",
+                  file=sys.stderr)
+        made = [None] * world
+        dist.all_gather_object(made, group is not None)
+        if not all(made):
+            if group is not None:
+                group.close()
+                group = None
+            native = False
+            ss._make_exchange_buffers()
     recut_every = getattr(args, "recut_every", 0) or 0
 
     def run(nsteps):
