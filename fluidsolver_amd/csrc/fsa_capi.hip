@@ -961,15 +961,18 @@ int fsa_update_position(fsa_solver *hs) {
 int fsa_correct_density_error(fsa_solver *hs, int maxiter, double ethres, int *iterations, double *last_error) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    int iter = 0;
+    int iter = 0, rc = FSA_OK;
     double error = 0.0;
-    while (iter < maxiter) {
-        TRY(fsa_solve_density_stiff(hs));
-        TRY(launch_max_error(s, -9999.0, &error));  // solver/sph_solver.cu:176
-        if (error < ethres) break;
-        TRY(fsa_apply_pstiff(hs));
+    s->dfsph_chain = 1;  // the passes hand their packed records on to each other
+    while (iter < maxiter && !rc) {
+        rc = fsa_solve_density_stiff(hs);
+        if (!rc) rc = launch_max_error(s, -9999.0, &error);  // solver/sph_solver.cu:176
+        if (rc || error < ethres) break;
+        rc = fsa_apply_pstiff(hs);
         iter++;
     }
+    s->dfsph_chain = 0;
+    if (rc) return rc;
     TRY(fsa_update_position(hs));
     if (iterations) *iterations = iter;
     if (last_error) *last_error = error;
@@ -981,14 +984,17 @@ int fsa_correct_divergence_error(fsa_solver *hs, int maxiter, double ethres, int
     NEED(s);
     int iter = 0;
     double error = 0.0;
-    TRY(fsa_solve_divergence_stiff(hs));  // the extra first launch of solver/sph_solver.cu:226
-    while (iter < maxiter) {
-        TRY(fsa_solve_divergence_stiff(hs));
-        TRY(launch_max_error(s, 0.0, &error));
-        if (error < ethres) break;
-        TRY(fsa_apply_pstiff(hs));
+    s->dfsph_chain = 1;  // the passes hand their packed records on to each other
+    int rc = fsa_solve_divergence_stiff(hs);  // the extra first launch of solver/sph_solver.cu:226
+    while (iter < maxiter && !rc) {
+        rc = fsa_solve_divergence_stiff(hs);
+        if (!rc) rc = launch_max_error(s, 0.0, &error);
+        if (rc || error < ethres) break;
+        rc = fsa_apply_pstiff(hs);
         iter++;
     }
+    s->dfsph_chain = 0;
+    if (rc) return rc;
     TRY(fsa_update_velocities(hs));
     if (iterations) *iterations = iter;
     if (last_error) *last_error = error;

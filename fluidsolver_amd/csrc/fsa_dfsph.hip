@@ -115,9 +115,23 @@ template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct Stif
     struct Self { T acc; Vec3<T> vs; };
     struct Nb { T vx, vy, vz, mass; };
     static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
+    // what applyPStiff reads of this particle, as pack_pstiff_mass_kernel writes it
+    static __device__ __forceinline__ void record(const PassArrays<T> &A, int index, T ps) {
+        if (A.rec2Out) {
+            const T mass = reinterpret_cast<const T *>(A.velMass)[4 * (size_t)index + 3];
+            const T w = ps / A.density[index];
+            if constexpr (sizeof(T) == 4) {
+                reinterpret_cast<float2 *>(A.rec2Out)[index] = make_float2(w, mass);
+            } else {
+                A.rec2Out[2 * (size_t)index] = w;
+                A.rec2Out[2 * (size_t)index + 1] = mass;
+            }
+        }
+    }
     static __device__ __forceinline__ void skip(const PassArrays<T> &A, const DevParams<T> &, int index) {
         A.errorOut[index] = 0;
         A.pstiffOut[index] = 0;
+        record(A, index, (T)0);
     }
     static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
         S.acc = TIMES_DT ? A.density[index] : (T)0;
@@ -168,11 +182,14 @@ template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct Stif
             }
             A.pstiffOut[index] = ps;
             A.errorOut[index] = err;
+            record(A, index, ps);
         } else {
             T densChange = S.acc;
             if (densChange < 0) densChange = 0;
             A.errorOut[index] = densChange / rd;
-            A.pstiffOut[index] = densChange / P.dt * A.dfFactor[index];
+            const T ps = densChange / P.dt * A.dfFactor[index];
+            A.pstiffOut[index] = ps;
+            record(A, index, ps);
         }
     }
 };
@@ -229,6 +246,8 @@ template <typename T, bool PACKED, bool FAST = false> struct ApplyPolicy {
         vs.y += S.fy * P.dt * (T)(-1);
         vs.z += S.fz * P.dt * (T)(-1);
         A.vStarOut[index] = vs;
+        if (A.recOut)  // what the density-change passes read of this particle, as pack_vstar_mass_kernel writes it
+            A.recOut[index] = Vec4<T>{vs.x, vs.y, vs.z, reinterpret_cast<const T *>(A.velMass)[4 * (size_t)index + 3]};
     }
 };
 
@@ -389,13 +408,32 @@ int launch_non_pressure_force(Solver *s) {
     return FSA_OK;
 }
 
+// The tuned passes read packed records that a small kernel writes first.  Inside fsa_correct_density_error /
+// fsa_correct_divergence_error (Solver::dfsph_chain) the passes hand the records on to each other instead: a
+// density-change pass also writes what applyPStiff reads of each particle, applyPStiff what the next density-change
+// pass reads, and only the first pass of a loop packs.  Same records, same bits.
+template <typename Policy> static int run_stiff(Solver *s, const char *tag) {
+    if (s->dfsph_chain != 2) {
+        int rc = pack_vstar_mass(s);
+        if (rc) return rc;
+    }
+    int rc = ensure_lists(s);
+    if (rc) return rc;
+    PassArrays<float> A = arrays_of<float>(s);
+    if (s->dfsph_chain) {
+        s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
+        A.rec2Out = (float *)s->b.pd;
+        s->dfsph_chain = 2;
+    }
+    ScopedTimer t(s, tag);
+    return run_tiled<Policy>(s, A, true);
+}
+
 int launch_solve_density_stiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
     if (use_tiles(s)) {
-        int rc = pack_vstar_mass(s);
-        if (rc) return rc;
-        if (use_fast(s)) return launch_tuned<StiffPolicy<float, true, true, true>>(s, "density_stiff", true);
-        return launch_tuned<StiffPolicy<float, true, true>>(s, "density_stiff", true);
+        if (use_fast(s)) return run_stiff<StiffPolicy<float, true, true, true>>(s, "density_stiff");
+        return run_stiff<StiffPolicy<float, true, true>>(s, "density_stiff");
     }
     // (these policy names carry commas, which a macro argument cannot: hence the alias macro)
 #define FSA_POLICY StiffPolicy<T, true, false>
@@ -407,10 +445,8 @@ int launch_solve_density_stiff(Solver *s) {
 int launch_solve_divergence_stiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
     if (use_tiles(s)) {
-        int rc = pack_vstar_mass(s);
-        if (rc) return rc;
-        if (use_fast(s)) return launch_tuned<StiffPolicy<float, false, true, true>>(s, "divergence_stiff", true);
-        return launch_tuned<StiffPolicy<float, false, true>>(s, "divergence_stiff", true);
+        if (use_fast(s)) return run_stiff<StiffPolicy<float, false, true, true>>(s, "divergence_stiff");
+        return run_stiff<StiffPolicy<float, false, true>>(s, "divergence_stiff");
     }
 #define FSA_POLICY StiffPolicy<T, false, false>
     DF_GENERIC(FSA_POLICY, "divergence_stiff");
@@ -421,7 +457,8 @@ int launch_solve_divergence_stiff(Solver *s) {
 int launch_apply_pstiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
     if (use_tiles(s)) {
-        {
+        const bool chained = s->dfsph_chain == 2;  // the density-change pass before has written the records
+        if (!chained) {
             ScopedTimer t(s, "pack_pstiff_mass");
             s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
             hipLaunchKernelGGL(pack_pstiff_mass_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
@@ -429,8 +466,13 @@ int launch_apply_pstiff(Solver *s) {
                                (const float4 *)s->b.velMass[s->cur], (float2 *)s->b.pd);
             FSA_HIP(hipGetLastError());
         }
-        if (use_fast(s)) return launch_tuned<ApplyPolicy<float, true, true>>(s, "apply_pstiff", true);
-        return launch_tuned<ApplyPolicy<float, true>>(s, "apply_pstiff", true);
+        int rc = ensure_lists(s);
+        if (rc) return rc;
+        PassArrays<float> A = arrays_of<float>(s);
+        if (chained) A.recOut = (float4 *)s->b.aux4;
+        ScopedTimer t(s, "apply_pstiff");
+        if (use_fast(s)) return run_tiled<ApplyPolicy<float, true, true>>(s, A, true);
+        return run_tiled<ApplyPolicy<float, true>>(s, A, true);
     }
 #define FSA_POLICY ApplyPolicy<T, false>
     DF_GENERIC(FSA_POLICY, "apply_pstiff");

@@ -30,6 +30,7 @@ template <typename T> struct PassArrays {
     const Vec4<T> *aux4b; // a second packed record per particle (IISPH pressure rounds)
     Vec4<T> *recOut;      // where a pass writes the record the NEXT pass reads of this particle (null: nowhere)
     const T *aux2;        // {pstiff / density, mass} pairs (tuned applyPStiff)
+    T *rec2Out;           // like recOut, for a two-word record (null: nowhere)
     T *densityOut;
     T *dfFactorOut;
     T *errorOut;

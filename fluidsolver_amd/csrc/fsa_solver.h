@@ -124,6 +124,7 @@ struct Solver {
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     int iisph_chain = 0;        // inside fsa_iisph_solve_pressure: 1 first round, 2 later rounds (fsa_iisph.hip)
+    int dfsph_chain = 0;        // inside the two DFSPH correction loops: 1 before the first pass, 2 after (fsa_dfsph.hip)
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)
     int force_zone = 0;  // variant-3 force pass: 0 all blocks, 1 only those that touch an edge (DevParams::edge), 2 the rest

@@ -119,6 +119,50 @@ def test_correction_loops(pair):
     assert rel_err(s.get("vel"), st["vel"]) <= 10 * tol
 
 
+@pytest.mark.parametrize("name", ["dam_walls", "compressed"])
+def test_correction_loops_equal_their_stage_calls_bit_for_bit(name):
+    """inside the two loops the passes hand their packed neighbour records on to each other instead of packing
+    them before every pass: same iteration counts and the same bits as the loop written out in stage calls"""
+    sc = scene(name)
+    _, a = gpu_solver(sc)
+    _, b = gpu_solver(sc)
+    for s in (a, b):
+        s.sort_particles()
+        s.compute_density_alpha()
+        s.compute_non_pressure_force()
+    it_a, e_a = a.correct_density_error(5, 1.0)
+    it_b = 0
+    while it_b < 5:
+        b.solve_density_stiff()
+        e_b = float(b.get("error").max())
+        if e_b < 1.0:
+            break
+        b.apply_pstiff()
+        it_b += 1
+    b.update_position()
+    assert it_a == it_b and it_a > 0
+    for k in ("pos", "v_star", "pstiff", "error"):
+        assert a.get(k).tobytes() == b.get(k).tobytes(), k
+    for s in (a, b):
+        s.sort_particles()
+        s.compute_density_alpha()
+    it_a, e_a = a.correct_divergence_error(5, 1.0)
+    it_b = 0
+    b.solve_divergence_stiff()
+    while it_b < 5:
+        b.solve_divergence_stiff()
+        if float(max(b.get("error").max(), 0.0)) < 1.0:
+            break
+        b.apply_pstiff()
+        it_b += 1
+    b.update_velocities()
+    assert it_a == it_b
+    for k in ("vel", "v_star", "pstiff", "error"):
+        assert a.get(k).tobytes() == b.get(k).tobytes(), k
+    a.close()
+    b.close()
+
+
 def test_five_dfsph_steps(pair):
     sc, p, st, s, tol = pair
     st.sort_particles(p)
