@@ -454,6 +454,22 @@ int fsa_upload(fsa_solver *hs, int n, const void *pos3, const void *vel3, const 
     s->has_rigid = false;
     for (size_t i = 0; i < N; i++)
         if (type[i] == FSA_TYPE_RIGID) s->has_rigid = true;
+    s->fluid_mass_uniform = false;
+    if (R == sizeof(float)) {  // one mass for all fluid particles? (bit patterns compared)
+        const unsigned *m = (const unsigned *)mass;
+        bool any = false, same = true;
+        unsigned first = 0;
+        for (size_t i = 0; i < N && same; i++) {
+            if (type[i] != FSA_TYPE_FLUID) continue;
+            if (!any) {
+                first = m[i];
+                any = true;
+            } else if (m[i] != first) {
+                same = false;
+            }
+        }
+        s->fluid_mass_uniform = any && same;
+    }
     s->n = n;
     s->cur = 0;
     invalidate_order(s);
@@ -710,6 +726,7 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
     }
     if (k == "type" || k == "mass") {
         TRY(want(k == "type" ? N * sizeof(int) : N * R));
+        s->fluid_mass_uniform = false;  // (not looked at again: the general kernels serve)
         Staging st;
         TRY(st.alloc(bytes));
         TRY(launch_unpack_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
@@ -1087,6 +1104,7 @@ int fsa_effective_mass(fsa_solver *hs) {
     if (s->slab) return fail(FSA_ERR_INVALID, "fsa_effective_mass is not available in a slab solver");
     if (s->typenum == 0) return fail(FSA_ERR_INVALID, "fsa_effective_mass needs fsa_set_volume_fractions first");
     s->pd_valid = false;
+    s->fluid_mass_uniform = false;  // the masses become per-particle values
     return launch_effective_mass(s);
 }
 

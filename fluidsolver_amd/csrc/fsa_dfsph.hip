@@ -163,6 +163,14 @@ struct NpfFastPolicy {
     }
 };
 
+// What applyPStiff reads of a neighbour when every fluid particle has the same mass (ApplyUniformPolicy below):
+// {x, y, z, pstiff / density}; a particle that is not fluid lies far outside any support.
+constexpr float kFarAway = 1e30f;
+__device__ __forceinline__ float4 apply_record(const float4 &p, float w) {
+    return unpack_int(p.w) == FSA_TYPE_FLUID ? make_float4(p.x, p.y, p.z, w)
+                                             : make_float4(kFarAway, kFarAway, kFarAway, 0.0f);
+}
+
 // ---- DensityChangeCell :775-813 / PredictDensityCell :846-887 and the two kernels around them -------
 // TIMES_DT = false: solveDivergenceStiff :818-842; true: solveDensityStiff :890-919
 // FAST (fp32, variant 2): hardware reciprocal square root and fused multiply-adds, about 1e-7 relative per term
@@ -175,6 +183,9 @@ template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct Stif
     static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
     // what applyPStiff reads of this particle, as pack_pstiff_mass_kernel writes it
     static __device__ __forceinline__ void record(const PassArrays<T> &A, int index, T ps) {
+        if constexpr (sizeof(T) == 4) {
+            if (A.recOut) A.recOut[index] = apply_record(A.posType[index], ps / A.density[index]);
+        }
         if (A.rec2Out) {
             const T mass = reinterpret_cast<const T *>(A.velMass)[4 * (size_t)index + 3];
             const T w = ps / A.density[index];
@@ -308,6 +319,54 @@ template <typename T, bool PACKED, bool FAST = false> struct ApplyPolicy {
             A.recOut[index] = Vec4<T>{vs.x, vs.y, vs.z, reinterpret_cast<const T *>(A.velMass)[4 * (size_t)index + 3]};
     }
 };
+
+// applyPStiff for scenes whose fluid particles all have one mass (Solver::fluid_mass_uniform), fast fp32 flavour: the
+// neighbour's mass is the particle's own, so everything the pass reads of a neighbour fits one 16-byte record (see
+// apply_record) and a neighbour costs one gather instead of two.  Same operations on the same values as
+// ApplyPolicy<float, true, true>: same bits.
+struct ApplyUniformPolicy {
+    using T = float;
+    static constexpr bool kPosInNb = true;
+    static constexpr bool kDeepReplay = true;
+    static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
+    struct Self { T wi, fx, fy, fz, mass; };
+    struct Nb {
+        float4 r;
+        __device__ __forceinline__ float4 pos() const { return make_float4(r.x, r.y, r.z, 0.0f); }  // type bits: fluid
+    };
+    static __device__ __forceinline__ bool wants(int type) { return type == FSA_TYPE_FLUID; }
+    static __device__ __forceinline__ void skip(const PassArrays<T> &, const DevParams<T> &, int) {}
+    static __device__ __forceinline__ void init(const PassArrays<T> &A, const DevParams<T> &, int index, Self &S) {
+        S.wi = A.pstiffIn[index] / A.density[index];
+        S.mass = A.velMass[index].w;
+        S.fx = S.fy = S.fz = 0;
+    }
+    static __device__ __forceinline__ Nb load(const PassArrays<T> &A, int j) { return Nb{A.aux4b[j]}; }
+    static __device__ __forceinline__ void pair(const PassArrays<T> &, const DevParams<T> &P, Self &S, bool self, int,
+                                                int, T xx, T xy, T xz, T d2, const Vec4<T> &, const Nb &nb) {
+        if (self) return;
+        const T sr = P.sr, sr2 = sr * sr;
+        if (d2 >= sr2) return;
+        const float rinv = __builtin_amdgcn_rsqf(d2);
+        const float c = sr - d2 * rinv;
+        const float f = P.kspikydiff * c * c * rinv * S.mass * (S.wi + nb.r.w);
+        S.fx = __builtin_fmaf(xx, f, S.fx);
+        S.fy = __builtin_fmaf(xy, f, S.fy);
+        S.fz = __builtin_fmaf(xz, f, S.fz);
+    }
+    static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
+        ApplyPolicy<float, true, true>::Self S0{S.wi, S.fx, S.fy, S.fz};
+        ApplyPolicy<float, true, true>::finish(A, P, index, S0);
+    }
+};
+__global__ __launch_bounds__(kBlock) void pack_apply_record_kernel(int n, const float4 *__restrict__ posType,
+                                                                   const float *__restrict__ pstiff,
+                                                                   const float *__restrict__ density,
+                                                                   float4 *__restrict__ rec) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    rec[i] = apply_record(posType[i], pstiff[i] / density[i]);
+}
 
 // ---- DensityCell :203-244 + ComputePressureKernel :246-266, TYPE_RIGID term included ---------------
 // (the dedicated WCSPH density kernel of fsa_sph_tuned.hip leaves that term out and is used for scenes
@@ -476,6 +535,8 @@ int launch_non_pressure_force(Solver *s) {
     return FSA_OK;
 }
 
+static bool apply_uniform(const Solver *s) { return use_fast(s) && s->fluid_mass_uniform && s->b.hitWords; }
+
 // The tuned passes read packed records that a small kernel writes first.  Inside fsa_correct_density_error /
 // fsa_correct_divergence_error (Solver::dfsph_chain) the passes hand the records on to each other instead: a
 // density-change pass also writes what applyPStiff reads of each particle, applyPStiff what the next density-change
@@ -489,8 +550,13 @@ template <typename Policy> static int run_stiff(Solver *s, const char *tag) {
     if (rc) return rc;
     PassArrays<float> A = arrays_of<float>(s);
     if (s->dfsph_chain) {
-        s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
-        A.rec2Out = (float *)s->b.pd;
+        if (apply_uniform(s)) {
+            s->hits_valid = false;  // the records live in the buffer of the WCSPH hit record, which this step does not use
+            A.recOut = (float4 *)s->b.hitWords;
+        } else {
+            s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
+            A.rec2Out = (float *)s->b.pd;
+        }
         s->dfsph_chain = 2;
     }
     ScopedTimer t(s, tag);
@@ -524,6 +590,24 @@ int launch_solve_divergence_stiff(Solver *s) {
 
 int launch_apply_pstiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
+    if (apply_uniform(s)) {
+        const bool chained = s->dfsph_chain == 2;  // the density-change pass before has written the records
+        if (!chained) {
+            ScopedTimer t(s, "pack_pstiff_mass");
+            s->hits_valid = false;
+            hipLaunchKernelGGL(pack_apply_record_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
+                               (const float4 *)s->b.posType[s->cur], (const float *)s->b.pstiff,
+                               (const float *)s->b.density, (float4 *)s->b.hitWords);
+            FSA_HIP(hipGetLastError());
+        }
+        int rc = ensure_lists(s);
+        if (rc) return rc;
+        PassArrays<float> A = arrays_of<float>(s);
+        A.aux4b = (const float4 *)s->b.hitWords;
+        if (chained) A.recOut = (float4 *)s->b.aux4;
+        ScopedTimer t(s, "apply_pstiff");
+        return run_tiled<ApplyUniformPolicy>(s, A, true);
+    }
     if (use_tiles(s)) {
         const bool chained = s->dfsph_chain == 2;  // the density-change pass before has written the records
         if (!chained) {

@@ -124,6 +124,7 @@ struct Solver {
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     int iisph_chain = 0;        // inside fsa_iisph_solve_pressure: 1 first round, 2 later rounds (fsa_iisph.hip)
+    bool fluid_mass_uniform = false;  // fp32: every TYPE_FLUID particle has the same mass (checked where the host hands the masses over)
     int dfsph_chain = 0;        // inside the two DFSPH correction loops: 1 before the first pass, 2 after (fsa_dfsph.hip)
     bool slab = false;             // holds a z-slab of the grid: order keys are maintained
     bool owned_from_sort = false;  // sortedHash describes the current arrays (tells owned from halo copies)

@@ -18,10 +18,13 @@ def scene(name):
     pos = np.array(sc["pos"])
     pos[fl] = (pos[fl] - pos[fl].min(0)) * np.float32(0.96) + pos[fl].min(0)  # compressed: the solvers have work
     sc["pos"] = pos
+    if name == "compressed_masses":  # not one mass for all fluid particles: the general applyPStiff kernels
+        rng = np.random.Generator(np.random.PCG64(23))
+        sc["mass"] = (np.asarray(sc["mass"]) * rng.uniform(0.95, 1.05, len(pos))).astype(np.float32)
     return sc
 
 
-@pytest.fixture(params=[("dam_walls", "f32"), ("compressed", "f32"), ("compressed", "f64")],
+@pytest.fixture(params=[("dam_walls", "f32"), ("compressed", "f32"), ("compressed_masses", "f32"), ("compressed", "f64")],
                 ids=lambda p: f"{p[0]}-{p[1]}")
 def pair(request, orc32, orc64):
     name, prec = request.param
@@ -119,7 +122,7 @@ def test_correction_loops(pair):
     assert rel_err(s.get("vel"), st["vel"]) <= 10 * tol
 
 
-@pytest.mark.parametrize("name", ["dam_walls", "compressed"])
+@pytest.mark.parametrize("name", ["dam_walls", "compressed", "compressed_masses"])
 def test_correction_loops_equal_their_stage_calls_bit_for_bit(name):
     """inside the two loops the passes hand their packed neighbour records on to each other instead of packing
     them before every pass: same iteration counts and the same bits as the loop written out in stage calls"""
@@ -158,6 +161,22 @@ def test_correction_loops_equal_their_stage_calls_bit_for_bit(name):
     b.update_velocities()
     assert it_a == it_b
     for k in ("vel", "v_star", "pstiff", "error"):
+        assert a.get(k).tobytes() == b.get(k).tobytes(), k
+    a.close()
+    b.close()
+
+
+def test_one_mass_for_all_fluid_flavour_of_apply_pstiff_gives_the_same_bits():
+    """with one mass for every fluid particle applyPStiff reads a single packed record per neighbour; handing the
+    same masses over again with set() switches that off: both ways must agree bit for bit"""
+    sc = scene("compressed")
+    _, a = gpu_solver(sc)
+    _, b = gpu_solver(sc)
+    b.set("mass", np.asarray(sc["mass"], np.float32))
+    for s in (a, b):
+        s.setup_dfsph()
+        s.step_dfsph(3)
+    for k in ("pos", "vel", "v_star", "pstiff"):
         assert a.get(k).tobytes() == b.get(k).tobytes(), k
     a.close()
     b.close()
