@@ -56,7 +56,30 @@ struct SlabRanges {
     int keep_lo, keep_hi;    // layers this solver will hold next (halo included)
     int left_lo, left_hi;    // layers the left neighbour will hold next
     int right_lo, right_hi;  // same for the right neighbour
+    int next_lo, next_hi;    // layers this solver will own next (see slab_ranges)
 };
+
+// The layers a solver owns next follow from what it and its neighbours hold next: a neighbour's range reaches `halo`
+// layers into this solver's own, this solver's range `halo` layers beyond it (slabs are at least halo + 1 thick, so
+// nothing of that is clipped by the grid); without a neighbour the own layers end where the held ones do.
+static SlabRanges slab_ranges(const int own[2], const int keep[2], const int left[2], const int right[2]) {
+    SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1], keep[0], keep[1]};
+    if (left[1] > left[0]) R.next_lo = (keep[0] + left[1]) / 2;
+    if (right[1] > right[0]) R.next_hi = (right[0] + keep[1]) / 2;
+    return R;
+}
+
+// A particle outside the grid is nobody's neighbour (it is in no cell) and is never sent as a halo copy, but its own
+// sums run over the cells around it.  So it is filed under the cell layer of its z coordinate, clamped into the grid,
+// lives with the slab that owns that layer, and moves on -- one slab per step -- when it drifts past a cut.
+template <typename T> __device__ __forceinline__ int outside_layer(const DevParams<T> &P, T z) {
+    const int cz = to_int_sat(r_floor((z - P.gmin[2]) / P.dx));
+    return min(max(cz, 0), P.gres[2] - 1);
+}
+// bit 0 keep, 1 left, 2 right
+__device__ __forceinline__ unsigned route_outside(const SlabRanges &R, int layer) {
+    return layer < R.next_lo ? 2u : (layer >= R.next_hi ? 4u : 1u);
+}
 
 constexpr int kPackItems = 4;  // particles per thread: one atomic per stream for 1024 particles
 
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
                     inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
                 }
                 if (!inside) {
-                    flags[k] = 1;  // out-of-grid particles stay with their owner
+                    flags[k] = route_outside(R, outside_layer(P, p[k].z));
                 } else {
                     if (cz >= R.keep_lo && cz < R.keep_hi) flags[k] |= 1;
                     if (cz >= R.left_lo && cz < R.left_hi) flags[k] |= 2;
@@ -350,7 +373,9 @@ __device__ __forceinline__ void owned_and_edge(const DevParams<float> &P, const 
     if (!all_owned) {
         const unsigned h = (unsigned)sortedHash[i];
         if (h == FSA_GRID_UNDEF) {
-            owned = true;  // halo copies are always inside the grid when they arrive; such a particle goes nowhere
+            // (halo copies are always inside the grid when they arrive.)  Where such a particle drifts, no layer of
+            // the last sort tells: it goes through the edge pass
+            owned = edge = true;
         } else {
             const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
             owned = gz >= R.own_lo && gz < R.own_hi;
@@ -368,7 +393,7 @@ __device__ __forceinline__ unsigned classify(const DevParams<float> &P, const Sl
         calc_grid_pos(P, p.x, p.y, p.z, cx, cy, cz);
         inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
     }
-    if (!inside) return 1u;  // out-of-grid particles stay with their owner
+    if (!inside) return route_outside(R, outside_layer(P, p.z));
     unsigned flags = 0;
     if (cz >= R.keep_lo && cz < R.keep_hi) flags |= 1u;
     if (cz >= R.left_lo && cz < R.left_hi) flags |= 2u;
@@ -453,7 +478,11 @@ __global__ __launch_bounds__(kBlock) void slab_keep_hash_kernel(
     int *__restrict__ slot, int *__restrict__ cellCount, int *__restrict__ undefBlockCount) {
     __shared__ int waveCount[kBlock / 64];
     const int n = live_count(P, bound);
-    if ((int)blockIdx.x * kBlock >= n) return;
+    if ((int)blockIdx.x * kBlock >= n) {
+        // slots the next unpack may append to: their blocks start without out-of-grid particles
+        if (threadIdx.x == 0) undefBlockCount[blockIdx.x] = 0;
+        return;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -526,19 +555,27 @@ __global__ __launch_bounds__(kBlock) void slab_unpack_hash_kernel(
         restDensity[i] = r.restDensity;
         uniqueId[i] = r.uniqueId;
         key[i] = r.orderKey;
-        if (in_domain(P, r.posType.x, r.posType.y, r.posType.z)) {
-            int cx, cy, cz;
+        bool inside = in_domain(P, r.posType.x, r.posType.y, r.posType.z);
+        int cx = 0, cy = 0, cz = 0;
+        if (inside) {
             calc_grid_pos(P, r.posType.x, r.posType.y, r.posType.z, cx, cy, cz);
+            inside = cx >= 0 && cx < P.gres[0] && cy >= 0 && cy < P.gres[1] && cz >= 0 && cz < P.gres[2];
+        }
+        if (inside) {
             h = calc_grid_hash(P, cx, cy, cz);
+            if (h == FSA_GRID_UNDEF) {  // not in the layers held here: nobody should have sent it
+                h = kHashDrop;
+                atomicAdd(vars + kVarLost, 1);
+            }
+        } else {
+            h = FSA_GRID_UNDEF;  // an out-of-grid particle that drifted past the cut: it lives here now
         }
-        if (h == FSA_GRID_UNDEF || h == kHashDrop) {  // not in the layers held here: nobody should have sent it
-            h = kHashDrop;
-            atomicAdd(vars + kVarLost, 1);
-        }
-        // out-of-grid ranks are kept per block of kBlock slots; the blocks that begin in the appended part have none
-        if (i % kBlock == 0) undefBlockCount[i / kBlock] = 0;
     }
-    const int my = count_in_cell(valid && h != kHashDrop, h, cellCount);
+    const bool in_cell = valid && h != kHashDrop && h != FSA_GRID_UNDEF;
+    int my = count_in_cell(in_cell, h, cellCount);
+    // out-of-grid ranks are kept per block of kBlock slots (the keep pass has counted the slots below `at` and
+    // zeroed the blocks above): an arrival takes the next rank of its block
+    if (valid && h == FSA_GRID_UNDEF) my = atomicAdd(undefBlockCount + i / kBlock, 1);
     if (valid) {
         hash[i] = (int)h;
         slot[i] = my;
@@ -598,7 +635,7 @@ int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int l
     FSA_HIP(hipMemsetAsync(s->b.slabCounters, 0, 4 * sizeof(int), s->stream));
     if (s->n > 0) {
         ScopedTimer t(s, "slab_pack");
-        SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1]};
+        const SlabRanges R = slab_ranges(own, keep, left, right);
         int rc = s->precision == FSA_PRECISION_F32
                      ? pack_t<float>(s, s->pf, R, sendLeft, capLeft, sendRight, capRight)
                      : pack_t<double>(s, s->pd, R, sendLeft, capLeft, sendRight, capRight);
@@ -656,7 +693,8 @@ int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const i
                           void *sendLeft, int sizeLeft, void *sendRight, int sizeRight) {
     const int rb = slab_record_bytes(s), c = s->cur, n = s->grid_n();
     ScopedTimer t(s, "edge_send");
-    SlabRanges R{own[0], own[1], s->pf.z0, s->pf.z0 + s->pf.nz, left[0], left[1], right[0], right[1]};
+    const int held[2] = {s->pf.z0, s->pf.z0 + s->pf.nz};
+    const SlabRanges R = slab_ranges(own, held, left, right);
     char *l = (char *)sendLeft, *r = (char *)sendRight;
 #define FSA_ES(ADV)                                                                                                  \
     hipLaunchKernelGGL(slab_edge_send_kernel<ADV>, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->pf, n,        \
@@ -693,7 +731,7 @@ int launch_slab_keep_hash(Solver *s, bool with_advect, const int own[2], const i
     }
     s->counts_clean = false;
     ScopedTimer t(s, with_advect ? "advect_keep_hash" : "keep_hash");
-    SlabRanges R{own[0], own[1], keep[0], keep[1], left[0], left[1], right[0], right[1]};
+    const SlabRanges R = slab_ranges(own, keep, left, right);
 #define FSA_KH(ADV)                                                                                                  \
     hipLaunchKernelGGL(slab_keep_hash_kernel<ADV>, dim3(blocks_for(n)), dim3(kBlock), 0, s->stream, s->pf, n,        \
                        s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (float4 *)s->b.posType[c],                    \

@@ -31,6 +31,14 @@ int cell_layer(const cfloat3 &p, const fsa_params &P) {
     return cell[2];
 }
 
+// the layer a particle outside the grid is filed under: that of its z coordinate, clamped into the grid (it lives
+// with the slab that owns this layer, as in the library's exchange kernels)
+int outside_layer(const cfloat3 &p, const fsa_params &P) {
+    const float c = std::floor((p.z - (float)P.gridxmin[2]) / (float)P.dx);
+    if (!(c == c) || c < 0.f) return 0;
+    return c >= (float)P.gridres[2] ? P.gridres[2] - 1 : (int)c;
+}
+
 // cut indices that balance the particle counts, every slab at least min_layers thick
 std::vector<int> balanced_cuts(const std::vector<long long> &hist, int nranks, int min_layers) {
     const int gz = (int)hist.size();
@@ -92,13 +100,17 @@ void SPHSolver::EnterSlabMode(int nslabs) {
     fsa_destroy(device);
     device = nullptr;
 
-    veci layer((size_t)n);
+    veci layer((size_t)n);  // the layer each particle is filed under
     std::vector<long long> hist((size_t)gz, 0);
     long long outside = 0;
     for (int i = 0; i < n; i++) {
         layer[i] = cell_layer(p[i], hParam);
-        if (layer[i] >= 0) hist[layer[i]]++;
-        else outside++;
+        if (layer[i] >= 0) {
+            hist[layer[i]]++;
+        } else {
+            outside++;
+            layer[i] = outside_layer(p[i], hParam);
+        }
     }
     slab_cuts = nslabs > 1 ? balanced_cuts(hist, nslabs, kHalo + 1) : std::vector<int>{0, gz};
     std::vector<long long> pre((size_t)gz + 1, 0);
@@ -135,7 +147,7 @@ void SPHSolver::EnterSlabMode(int nslabs) {
         vecf sm, srd;
         veci st, sid;
         for (int i = 0; i < n; i++) {
-            const bool mine = (layer[i] >= slab_cuts[r] && layer[i] < slab_cuts[r + 1]) || (r == 0 && layer[i] < 0);
+            const bool mine = layer[i] >= slab_cuts[r] && layer[i] < slab_cuts[r + 1];
             if (!mine) continue;
             sp.push_back(p[i]);
             sv.push_back(v[i]);

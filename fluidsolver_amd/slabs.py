@@ -47,6 +47,27 @@ def cell_layer_host(pos, vmin, vmax, dx, gridres):
     return np.where(inside, cell[2], -1)
 
 
+def owner_layer_host(pos, vmin, vmax, dx, gridres):
+    """The cell layer a particle is filed under for ownership: its cell layer, or, outside the grid (where
+    cell_layer_host gives -1), the layer of its z coordinate clamped into the grid.  Such a particle is nobody's
+    neighbour, but its own sums run over the cells around it: it lives with the slab that owns this layer."""
+    pos = np.asarray(pos)
+    layer = cell_layer_host(pos, vmin, vmax, dx, gridres)
+    dt = pos.dtype.type
+    with np.errstate(invalid="ignore"):
+        cz = np.floor((pos[:, 2] - dt(vmin[2])) / dt(dx))
+    cz = np.clip(np.nan_to_num(cz, nan=0.0), 0, gridres[2] - 1).astype(np.int64)
+    return np.where(layer >= 0, layer, cz)
+
+
+def next_own(keep, left, right):
+    """The layers a slab owns next, from the layers it and its two neighbours hold next (empty range: no
+    neighbour): a neighbour's range reaches `halo` layers into the slab's own, its own `halo` layers beyond."""
+    lo = (keep[0] + left[1]) // 2 if left[1] > left[0] else keep[0]
+    hi = (right[0] + keep[1]) // 2 if right[1] > right[0] else keep[1]
+    return lo, hi
+
+
 def z_layer_host(z, vmin_z, vmax_z, dx, gz):
     """cell_layer_host for z coordinates alone (positions known to be inside the grid box in x and y)."""
     z = np.asarray(z, dtype=np.float32)
@@ -338,10 +359,9 @@ class SlabSolver:
         self.layout = SlabLayout(gz, cuts, halo)
         own, held = self.layout.own(rank), self.layout.held(rank)
         self.own, self.held_layers = own, held
-        # out-of-grid particles start on rank 0
-        mine = (layer >= own[0]) & (layer < own[1])
-        if rank == 0:
-            mine |= layer < 0
+        # (out-of-grid particles go by the layer of their clamped z coordinate)
+        filed = owner_layer_host(pos, geo["vmin"], geo["vmax"], self.dx, self.gridres)
+        mine = (filed >= own[0]) & (filed < own[1])
         pre = np.concatenate([[0], np.cumsum(hist)])
         held_counts = [pre[self.layout.held(r)[1]] - pre[self.layout.held(r)[0]] for r in range(world)]
         n_outside = int((layer < 0).sum())
@@ -389,6 +409,8 @@ class SlabSolver:
         inside = ((p64 < hi.double() - 1e-10) & (p64 > lo.double() + 1e-10)).all(1)
         cell = torch.floor((pos - lo) / dx).long()
         inside &= ((cell >= 0) & (cell < res)).all(1)
+        self._record_filed = torch.where(inside, cell[:, 2], torch.nan_to_num(torch.floor((pos[:, 2] - lo[2]) / dx))
+                                         .clamp(0, self.gridres[2] - 1).long())  # see owner_layer_host
         return torch.where(inside, cell[:, 2], torch.full_like(cell[:, 2], -1))
 
     def rebalance(self):
@@ -414,8 +436,7 @@ class SlabSolver:
             if cuts == self.layout.cuts:
                 return False
             bounds = torch.tensor(cuts[1:-1], dtype=torch.int64, device=layer.device)
-            owner = torch.bucketize(layer, bounds, right=True)
-            owner = torch.where(layer < 0, torch.full_like(owner, self.rank), owner)
+            owner = torch.bucketize(self._record_filed, bounds, right=True)
             chunks = {d: rec[owner == d].reshape(-1) for d in range(self.world)}
             got = self.transport.redistribute({d: t for d, t in chunks.items() if d != self.rank}, rb)
             got[self.rank] = chunks[self.rank]

@@ -343,8 +343,11 @@ int fsa_set_neighbour_lists(fsa_solver *s, int enabled);
  * 0..n-1 in upload order.
  *
  * A slab solver does not store color / normal / group / indexTable (uniqueId is a global id there):
- * fsa_upload wants NULL for them and skips the permutation check.  The order of out-of-grid particles
- * at the tail of the arrays is unspecified in a slab run.
+ * fsa_upload wants NULL for them and skips the permutation check.  A particle outside the grid is nobody's
+ * neighbour and is never a halo copy, but its own sums run over the cells around it: it is filed under the cell
+ * layer of its z coordinate, clamped into the grid, lives with the slab that owns that layer and moves on, one slab
+ * per step, when it drifts past a cut (a driver hands such particles out by the same rule at the start).  The order
+ * of out-of-grid particles at the tail of the arrays is unspecified in a slab run.
  *
  * Per step, between fsa_advect and the next fsa_calc_hash:
  *   fsa_slab_pack    -> send the two record buffers to the neighbours (RCCL send/recv, the caller's job)
@@ -355,9 +358,11 @@ int fsa_slab_record_bytes(fsa_solver *s, int *bytes);
 /*
  * Classifies the particles this solver OWNED at the last sort (cell layer in [own[0], own[1]) then, or
  * outside the grid; all particles if no sort has run since the upload) by the cell layer they are in
- * now.  Those in [keep[0], keep[1]) -- and those outside the grid -- remain; those in
+ * now.  Those in [keep[0], keep[1]) remain; those in
  * [left[0], left[1]) / [right[0], right[1]) are written as records to the device buffers
- * d_send_left / d_send_right (cap_* records each); a particle may do several of these.  Everything
+ * d_send_left / d_send_right (cap_* records each); a particle may do several of these.  A particle outside
+ * the grid does exactly one of them, by the layer it is filed under (above) and the layers this solver owns
+ * next, which follow from the three ranges.  Everything
  * else the solver held (last step's halo copies) is dropped.  counts = {remaining, records left,
  * records right, lost}: `lost` counts owned particles that fit none of the ranges.  Synchronises.
  */

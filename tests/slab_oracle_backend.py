@@ -89,9 +89,15 @@ class OracleSlabBackend:
         now = self._layer_of_hash(st["particleHash"].copy())
         st.close()
         inside = now >= 0
-        k = owned & (~inside | ((now >= keep[0]) & (now < keep[1])))
-        l = owned & inside & (now >= left[0]) & (now < left[1])
-        r = owned & inside & (now >= right[0]) & (now < right[1])
+        # an out-of-grid particle lives with the slab that owns the layer of its clamped z coordinate
+        from fluidsolver_amd.slabs import next_own
+        with np.errstate(invalid="ignore"):
+            cz = np.floor((self.a["pos"][:, 2] - np.float32(self.p.gridxmin[2])) / np.float32(self.p.dx))
+        filed = np.clip(np.nan_to_num(cz, nan=0.0), 0, self.gres[2] - 1).astype(np.int64)
+        lo, hi = next_own(keep, left, right)
+        k = owned & np.where(inside, (now >= keep[0]) & (now < keep[1]), (filed >= lo) & (filed < hi))
+        l = owned & np.where(inside, (now >= left[0]) & (now < left[1]), filed < lo)
+        r = owned & np.where(inside, (now >= right[0]) & (now < right[1]), filed >= hi)
         lost = owned & inside & ~k & ~l & ~r
         for mask, buf, cap in ((l, buf_left, cap_left), (r, buf_right, cap_right)):
             m = int(mask.sum())

@@ -36,7 +36,37 @@ def ddam_scene():
     return sc
 
 
-SCENES = {"dam": test_scene, "ddam": ddam_scene}
+# cuts used with drift_scene (its grid has 22 cell layers)
+DRIFT_CUTS = {1: None, 2: [0, 11, 22], 3: [0, 7, 14, 22]}
+
+
+def drift_scene():
+    """the dam scene plus small clusters of fluid particles between the tank wall and the x-min face of the grid
+    box: half of each cluster starts just beyond that face and is held on it by the position clamp (out of the
+    grid: nobody's neighbour, but still feeling its mates next to it through viscosity), and all of them drift
+    along z across the cuts of DRIFT_CUTS, four cell layers in 25 steps"""
+    from fluidsolver_amd import slabs
+    sc = test_scene()
+    geo = slabs.derive_grid(sc["params"])
+    assert geo["gridres"][2] == 22
+    dx, xmin, zmin = float(geo["dx"]), float(geo["vmin"][0]), float(geo["vmin"][2])
+    pos, vel = np.array(sc["pos"], np.float32), np.array(sc["vel"], np.float32)
+    movers = np.nonzero(np.asarray(sc["type"]) == 0)[0][-24:]
+    k = 0
+    for cut in (7, 11, 14):
+        for side in (-1.0, 1.0):  # starting left of the cut and moving right, and the other way round
+            for j in range(4):
+                outside = j >= 2
+                i = movers[k]
+                k += 1
+                pos[i] = (xmin + (-0.2 if outside else 0.5) * dx, (0.05 if side < 0 else 0.09) + 0.5 * dx * (j % 2),
+                          zmin + (cut + 0.4 * side) * dx)
+                vel[i] = (0.0, 0.0 if outside else 0.3, -4.0 * side)
+    sc["pos"], sc["vel"] = pos, vel
+    return sc
+
+
+SCENES = {"dam": test_scene, "ddam": ddam_scene, "drift": drift_scene}
 
 
 def main():
@@ -74,6 +104,8 @@ def main():
     if a.recut_at:
         gz = slabs.derive_grid(sc["params"])["gridres"][2]
         cuts = [0] + [3 * (r + 1) for r in range(a.world - 1)] + [gz]
+    if a.scene == "drift":
+        cuts = DRIFT_CUTS[a.world]
     ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts)
     if a.recut_at:
         ss.step(a.recut_at)

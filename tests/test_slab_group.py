@@ -8,7 +8,7 @@ import pytest
 from fluidsolver_amd import capi, slabs
 from test_slabs_cpu import assert_same_bits, merged
 from test_slabs_gpu import plain_gpu_run
-from slab_worker import SCENES
+from slab_worker import DRIFT_CUTS, SCENES
 
 pytestmark = pytest.mark.gpu
 
@@ -20,12 +20,13 @@ def make_ranks(sc, world, cuts=None):
                              cuts=cuts, exchange_buffers=False) for r in range(world)]
 
 
-@pytest.mark.parametrize("scene", ["dam", "ddam"])
+@pytest.mark.parametrize("scene", ["dam", "ddam", "drift"])
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_local_group_equals_plain_solver(scene, world):
+    """(`drift`: with particles outside the grid that change owner as they drift along z past the cuts)"""
     sc = SCENES[scene]()
     ref = plain_gpu_run(sc, STEPS, 3)
-    ranks = make_ranks(sc, world)
+    ranks = make_ranks(sc, world, cuts=DRIFT_CUTS[world] if scene == "drift" else None)
     g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
                              max(ss.record_cap for ss in ranks))
     g.step(7)

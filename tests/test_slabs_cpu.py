@@ -77,6 +77,23 @@ def assert_same_bits(uid, got, ref):
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_out_of_grid_particles_move_on_with_their_z_layer(orc32, tmp_path, world):
+    """a particle outside the grid is nobody's neighbour but still sums over the cells around it: it has to live
+    with the slab that owns the layer of its z coordinate, and change owner when it drifts past a cut"""
+    steps = 25
+    parts = run_ranks(world, "oracle", steps, tmp_path, scene="drift")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    sc, ref = undivided(orc32, steps, scene="drift")
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, ref)
+    # the clusters really are outside at the end, on every rank, and feel their neighbours
+    for p in parts:
+        out = p["hash_layer"] < 0
+        assert out.sum() >= 2
+        assert np.abs(p["force"][out]).max() > 0  # (there is no gravity in this scene)
+
+
+@pytest.mark.parametrize("world", [2, 3])
 def test_slab_run_equals_undivided_run(orc32, tmp_path, world):
     steps = 25
     parts = run_ranks(world, "oracle", steps, tmp_path)

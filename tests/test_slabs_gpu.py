@@ -90,6 +90,16 @@ def test_double_dam_with_obstacles_two_ranks_recut(tmp_path):
     assert counts.max() / counts.mean() < 1.35
 
 
+def test_out_of_grid_particles_two_ranks(tmp_path):
+    """particles outside the grid drifting along z across the cut (stage-call exchange over gloo): plain run's bits"""
+    from slab_worker import drift_scene
+    parts = run_ranks(2, "hip", STEPS, tmp_path, variant=3, scene="drift")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, plain_gpu_run(drift_scene(), STEPS, 3))
+    assert all((p["hash_layer"] < 0).sum() >= 2 for p in parts)
+
+
 def test_slab_solver_rejects_static_attributes():
     from slab_worker import test_scene
     sc = test_scene()
