@@ -104,7 +104,7 @@ def main():
     if a.recut_at:
         gz = slabs.derive_grid(sc["params"])["gridres"][2]
         cuts = [0] + [3 * (r + 1) for r in range(a.world - 1)] + [gz]
-    if a.scene == "drift":
+    if a.scene == "drift" and not a.recut_at:
         cuts = DRIFT_CUTS[a.world]
     ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts)
     if a.recut_at:

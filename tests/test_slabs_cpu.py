@@ -121,6 +121,17 @@ def test_recut_mid_run_keeps_the_run_bit_identical(orc32, tmp_path):
     assert list(parts[0]["cuts"]) != [0, 3, 6, int(parts[0]["cuts"][-1])]
 
 
+def test_recut_with_particles_outside_the_grid(orc32, tmp_path):
+    """the re-cut hands particles outside the grid to the rank that owns the layer of their z coordinate"""
+    steps = 25
+    parts = run_ranks(3, "oracle", steps, tmp_path, recut_at=10, scene="drift")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    sc, ref = undivided(orc32, steps, scene="drift")
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, ref)
+    assert sum(int((p["hash_layer"] < 0).sum()) for p in parts) >= 6
+
+
 def test_double_dam_with_obstacles_recut(orc32, tmp_path):
     """the double dam break with box obstacles (uneven, shifting particle count per layer) over two ranks, from
     lopsided cuts, with one rebalance() on the way: still the undivided run bit for bit"""

@@ -100,6 +100,16 @@ def test_out_of_grid_particles_two_ranks(tmp_path):
     assert all((p["hash_layer"] < 0).sum() >= 2 for p in parts)
 
 
+def test_out_of_grid_particles_two_ranks_recut(tmp_path):
+    """the same from lopsided cuts with one rebalance() after 10 steps (fsa_slab_export_owned, records handed to the
+    rank that owns the layer of the particle's z coordinate)"""
+    from slab_worker import drift_scene
+    parts = run_ranks(2, "hip", STEPS, tmp_path, variant=3, recut_at=10, scene="drift")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, plain_gpu_run(drift_scene(), STEPS, 3))
+
+
 def test_slab_solver_rejects_static_attributes():
     from slab_worker import test_scene
     sc = test_scene()
