@@ -281,12 +281,13 @@ __global__ __launch_bounds__(256) void block_rows_kernel(DevParams<float> P, int
     const int blk = gid >> 4, r = gid & 15;
     const int nblk = (n + kTunedBS - 1) / kTunedBS;
     const bool live = blk < nblk;
-    int bad = 0, longest = 0;
+    int bad = 0, longest = 0, in_grid = 0;
     if (live) {
         const int b0 = blk * kTunedBS, nb = min(kTunedBS, n - b0);
         const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
         const bool grid_ok = hhi != (unsigned)FSA_GRID_UNDEF;
         bad = grid_ok ? 0 : 1;
+        in_grid = grid_ok ? 1 : 0;
         if (r < 9) {
             int s, len;
             block_row(P, hlo, hhi, grid_ok, r, cellStart, s, len);
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void block_rows_kernel(DevParams<float> P, int
         int *row = table + (size_t)blk * kRowTableStride;
         const int cls = bad ? 0 : (longest <= kRowCap ? 1 : 2);
         row[18] = cls;
-        row[19] = 0;
+        row[19] = (cls == 0 && in_grid) ? 1 : 0;  // rows too long as one range of cells: see sparse_segments (fsa_tile.h)
         if (cls == 2) big[1 + atomicAdd(&big[0], 1)] = blk;  // any order: the blocks are independent
     }
 }
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void rank_reorder_kernel(
         if (threadIdx.x == 0) {
             const int cls = bad ? 0 : (longest <= kRowCap ? 1 : 2);
             row[18] = cls;
-            row[19] = 0;
+            row[19] = (cls == 0 && grid_ok) ? 1 : 0;  // rows too long as one range of cells: see sparse_segments
             if (cls == 2) big[1 + atomicAdd(&big[0], 1)] = blk;  // any order: the blocks are independent
         }
     }

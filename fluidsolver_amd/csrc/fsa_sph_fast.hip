@@ -125,8 +125,10 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
     }
     if (tid < kMaxSegs) wallSeg[tid] = 0;
     const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
-    const bool staged = cls != 0;
+    bool staged = cls != 0, sparse = false;
     if (staged) setup_segments<ROWCAP>(sh, cls, sg);
+    else if (P.rows && P.rows[(size_t)blk * kRowTableStride + 19])  // rows too long as one range each (the tiles are free)
+        staged = sparse = sparse_segments<ROWCAP>(P, b0, nb, sortedHash, cellStart, reinterpret_cast<int *>(sh.x), sg);
 
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     float mass_i = 0.f, rd_i = 1.f;
@@ -217,11 +219,14 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
         float4 e[row_regs<BS, ROWCAP>()];
         int lj, le, nlj = 0, nle = 0;
         int rc0, rc1;
-        const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
-        fetch(sh.rowStartG[0], len0, e);
-        range_issue(0, rc0, rc1);
+        // the first segment is the head of row 0 (known before the segment table is visible), except in a block
+        // with segments of its own, whose table is
+        const int start0 = sparse ? sg.start[0] : sh.rowStartG[0];
+        const int len0 = sparse ? sg.len[0] : min(ROWCAP, sh.rowLen[0]);
+        fetch(start0, len0, e);
+        range_issue(sparse ? sg.row[0] : 0, rc0, rc1);
         bool wall = finish(0, len0, e);
-        range_finish(rc0, rc1, sh.rowStartG[0], len0, lj, le);
+        range_finish(rc0, rc1, start0, len0, lj, le);
         row_store<BS, ROWCAP, false>(sh, 0, e);
         __syncthreads();  // wallSeg cleared, segment table written
         if (wall) wallSeg[0] = 1;
@@ -506,8 +511,10 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
     // a block without fluid particles (wall layers) has nothing to do
     if (!__syncthreads_or(active ? 1 : 0)) return;
     const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, hlo, hhi, P.rows);
-    const bool staged = cls != 0;
+    bool staged = cls != 0, sparse = false;
     if (staged) setup_segments<ROWCAP>(sh, cls, sg);
+    else if (P.rows && P.rows[(size_t)blk * kRowTableStride + 19])  // the segments the density pass recorded with
+        staged = sparse = sparse_segments<ROWCAP>(P, b0, nb, sortedHash, cellStart, reinterpret_cast<int *>(tile.A), sg);
     int cnt = 0;       // extra words of the lane's record
     bool rec = false;  // the lane has a record
     if (active) {
@@ -565,8 +572,9 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
             tile.C[tid * ROWCAP] = 0.f;
         }
         __syncthreads();
-        const int len0 = min(ROWCAP, sh.rowLen[0]);  // the first segment is the head of row 0
-        fetch(sh.rowStartG[0], len0, e);
+        // the first segment is the head of row 0, or the first of the block's own segments
+        const int len0 = sparse ? sg.len[0] : min(ROWCAP, sh.rowLen[0]);
+        fetch(sparse ? sg.start[0] : sh.rowStartG[0], len0, e);
         uint2 fw = rec ? wp[0] : make_uint2(0u, 0u);  // main word of the segment whose loop runs
         store(0, len0, e);
         __syncthreads();

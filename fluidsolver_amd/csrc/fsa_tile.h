@@ -37,7 +37,9 @@ template <int BS, int ROWCAP, bool WITH_TYPE> struct RowShared {
 // every tiled pass until the next one: kRowTableStride ints per block = first particle of each of the 9 rows,
 // their lengths, and the block's class: 1 = every row in the grid and at most kRowCap long, 2 = at most
 // kRowCapBig long, 0 = neither (the block walks the cells particle by particle).  The ids of the class-2
-// blocks are also kept as a list (DevParams::big: count, then ids) for the launch that handles them.
+// blocks are also kept as a list (DevParams::big: count, then ids) for the launch that handles them.  The entry's
+// last int is 1 for a class-0 block that lies in the grid (its rows are too long as ranges of cells; the WCSPH
+// record kernels then try segments of their own, sparse_segments below).
 constexpr int kRowTableStride = 20;
 
 // Recorded neighbour lists: at most kListSlots entries per particle, 16 bits each (row << 9 | index in the row,
@@ -61,7 +63,8 @@ constexpr int kListOverflow = 0xffff;
 //                             pass of their own, where every lane is such a particle, sums their wall forces.
 // hitCount = number of extra words, kHitOverflow for a particle without a record, which walks the cells instead;
 // wallCount = number of wall words.
-constexpr int kMaxSegs = 18;  // a block's nine rows, the long ones as two tiles each (see Segments below)
+constexpr int kMaxSegs = 24;  // a block's nine rows, the long ones as two tiles each (18), or the segments of a
+                              // block whose particles lie in several stretches of cells (see Segments below)
 constexpr int kHitExtra = 6;
 constexpr int kHitWall = 14;
 constexpr int kHitSlots = kMaxSegs + kHitExtra + kHitWall;
@@ -222,6 +225,106 @@ __device__ __forceinline__ void setup_segments(const Shared &sh, int cls, Segmen
         }
         sg.count = k;
     }
+}
+
+// Segments of a block whose rows, taken as one range of cells from its first particle's cell to its last one's, are
+// too long for the tiles although the block needs little of them: 256 particles that lie in several stretches of
+// cells with other particles' cells in between (the end of one wall row, a nearly empty row and the start of a fluid
+// row; a splash).  The block's particles are cut into runs of adjacent cells (a new run where the cell index jumps
+// by more than 2, so that the neighbour cells of two runs never overlap); in each of the nine neighbour rows every
+// run needs the cells from one before its first to one after its last, and consecutive runs share a segment as long
+// as the range from the first's start to the last's end fits a tile (the particles in between ride along), else a new
+// segment starts; a single range longer than a tile is walked as several.  Segments come out in neighbour order
+// (row, then ascending index).  `scratch`: 20 * kSparseRuns + 16 ints of LDS that nobody else uses meanwhile.
+// Block-uniform result: false if there are more than kSparseRuns runs or more than kMaxSegs segments (the block then
+// walks the cells).  Ends with a barrier: the segment table is visible on return.
+constexpr int kSparseRuns = 16;
+template <int ROWCAP>
+__device__ __forceinline__ bool sparse_segments(const DevParams<float> &P, int b0, int nb,
+                                                const int *__restrict__ sortedHash, const int *__restrict__ cellStart,
+                                                int *scratch, Segments &sg) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *const lo = scratch, *const hi = lo + kSparseRuns;  // cell of the first / last particle of each run
+    int *const A = hi + kSparseRuns, *const B = A + 9 * kSparseRuns;  // [run][row]: the range a run needs of a row
+    int *const misc = B + 9 * kSparseRuns;  // [0..8] segments per row, then their prefix; [9] verdict; [10..13] heads per wavefront
+    const bool in = tid < nb;
+    const int h = in ? sortedHash[b0 + tid] : 0;
+    const bool head = in && (tid == 0 || h - sortedHash[b0 + tid - 1] > 2);
+    const bool tail = in && (tid == nb - 1 || sortedHash[b0 + tid + 1] - h > 2);
+    const unsigned long long hb = __ballot(head);
+    if (lane == 0) misc[10 + wave] = __popcll(hb);
+    __syncthreads();
+    int before = 0, nruns = 0;  // (256 threads: four wavefronts)
+    for (int w = 0; w < 4; w++) {
+        before += w < wave ? misc[10 + w] : 0;
+        nruns += misc[10 + w];
+    }
+    if (nruns > kSparseRuns) {
+        __syncthreads();  // (everyone has read misc before it may be reused)
+        return false;
+    }
+    const int upto = before + __popcll(hb & ((2ull << lane) - 1ull));  // heads up to and including this thread
+    if (head) lo[upto - 1] = h;
+    if (tail) hi[upto - 1] = h;
+    __syncthreads();
+    if (tid < 9 * nruns) {
+        const int k = tid / 9, r = tid % 9, C = P.num_cells;
+        const int dz = r / 3 - 1, dy = r % 3 - 1;
+        const long long off = (long long)dy * P.gres[0] * P.nz + (long long)dz * P.gres[0];
+        long long a = (long long)lo[k] + off - 1, b = (long long)hi[k] + off + 2;
+        a = a < 0 ? 0 : (a > C ? C : a);
+        b = b < 0 ? 0 : (b > C ? C : b);
+        A[tid] = cellStart[a];
+        B[tid] = cellStart[b];
+    }
+    __syncthreads();
+    // the same walk twice: first the segments of each row are counted, then written behind those of the rows before
+    auto walk = [&](int r, auto &&emit) {
+        auto tiles = [&](int a, int b) {
+            for (int o = a; o < b; o += ROWCAP) emit(o, min(ROWCAP, b - o));
+        };
+        int ca = A[r], cb = B[r];
+        for (int k = 1; k < nruns; k++) {
+            const int a = A[9 * k + r], b = B[9 * k + r];
+            if (b - ca <= ROWCAP) {
+                cb = b;
+            } else {
+                tiles(ca, cb);
+                ca = a;
+                cb = b;
+            }
+        }
+        tiles(ca, cb);
+    };
+    if (tid < 9) {
+        int c = 0;
+        walk(tid, [&](int, int) { c++; });
+        misc[tid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int r = 0; r < 9; r++) {
+            const int c = misc[r];
+            misc[r] = total;
+            total += c;
+        }
+        misc[9] = (total >= 1 && total <= kMaxSegs) ? total : 0;
+    }
+    __syncthreads();
+    const int total = misc[9];
+    if (total && tid < 9) {
+        int at = misc[tid];
+        walk(tid, [&](int s, int len) {
+            sg.start[at] = s;
+            sg.len[at] = len;
+            sg.row[at] = tid;
+            at++;
+        });
+    }
+    if (total && tid == 9) sg.count = total;
+    __syncthreads();
+    return total != 0;
 }
 
 // The lane's index range in row r, relative to the row's first particle (two loads of the cell table).
