@@ -5,7 +5,8 @@
 // The list of a particle holds, in the order of the reference's 27-cell walk (z, y, x cell loops, ascending
 // index inside a cell; solver/sph_kernel_impl.cuh:255-260), every particle of any type whose fused squared
 // distance is below the support radius squared times 1.000002, itself included, as 16-bit entries relative to
-// the row table of its block (row << 9 | index in the row; row << 10 | index for a block with large tiles).
+// the row table of its block (row << 9 | index in the row; row << 10 | index for a block with large tiles;
+// segment << 9 | index in the segment for a block with segments of its own, sparse_segments in fsa_tile.h).
 // Layout and limits: fsa_tile.h.
 #include <type_traits>
 
@@ -35,10 +36,29 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
     const bool active = index < n;
     const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, sh, 0u, 0u, P.rows);
     if (cls != 0 && cls != row_class<ROWCAP>()) return;  // the other instantiation's block
-    if (cls == 0) {  // the passes walk the cells for this block
-        if (active) counts[index] = (unsigned short)kListOverflow;
-        return;
+    // The tiles the cull walks: the block's nine rows, or, for a block whose particles lie in several stretches of
+    // cells (class 0 in the grid, fsa_tile.h), segments of its own; an entry is then segment << 9 | index.
+    __shared__ Segments sg;
+    if (cls == 0) {
+        bool sparse = false;
+        if constexpr (ROWCAP <= kRowCap) {
+            if (P.rows && P.rows[(size_t)blk * kRowTableStride + 19])
+                sparse = sparse_segments<ROWCAP>(P, b0, nb, sortedHash, cellStart, reinterpret_cast<int *>(sh.x), sg);
+        }
+        if (!sparse) {  // the passes walk the cells for this block
+            if (active) counts[index] = (unsigned short)kListOverflow;
+            return;
+        }
+    } else {
+        if (tid < 9) {
+            sg.start[tid] = sh.rowStartG[tid];
+            sg.len[tid] = sh.rowLen[tid];
+            sg.row[tid] = tid;
+        }
+        if (tid == 9) sg.count = 9;
+        __syncthreads();
     }
+    const int nseg = sg.count;
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) pi = posType[index];
     const float sr2c = P.sr * P.sr * 1.000002f;
@@ -70,17 +90,30 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
         cnt = rem;
     };
 
+    // the lane's index range in tile k: its cells of that row, as far as the tile holds them
+    auto seg_range = [&](int k, int &a, int &b) {
+        a = b = 0;
+        if (active) {
+            const int row = sg.row[k];
+            const int c = walk.row_cell(P, row % 3 - 1, row / 3 - 1);
+            if (c >= 0) {
+                const int s0 = sg.start[k], len = sg.len[k];
+                a = min(max(cellStart[c] - s0, 0), len);
+                b = min(max(cellStart[c + (walk.xhi - walk.xlo) + 1] - s0, 0), len);
+            }
+        }
+    };
     float4 e[row_regs<BS, ROWCAP>()];
     int lj, le, nlj = 0, nle = 0;
-    row_fetch<BS, ROWCAP, false>(sh, 0, posType, e);
-    lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+    tile_fetch<BS, ROWCAP, false>(sg.start[0], sg.len[0], posType, e);
+    seg_range(0, lj, le);
     row_store<BS, ROWCAP, false>(sh, 0, e);
     __syncthreads();
-    for (int r = 0; r < 9; r++) {
+    for (int r = 0; r < nseg; r++) {
         const int buf = r & 1;
-        if (r + 1 < 9) {  // in flight during the cull below
-            row_fetch<BS, ROWCAP, false>(sh, r + 1, posType, e);
-            lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+        if (r + 1 < nseg) {  // in flight during the cull below
+            tile_fetch<BS, ROWCAP, false>(sg.start[r + 1], sg.len[r + 1], posType, e);
+            seg_range(r + 1, nlj, nle);
         }
         const int tag = r << idx_bits<ROWCAP>();
         // One aligned group of four candidates; those with lo <= u < hi belong to the lane.
@@ -113,7 +146,7 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
             cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
             if (wave_any(cnt > Q - kChunk)) flush(false);
         }
-        if (r + 1 < 9) {
+        if (r + 1 < nseg) {
             row_store<BS, ROWCAP, false>(sh, buf ^ 1, e);
             lj = nlj;
             le = nle;

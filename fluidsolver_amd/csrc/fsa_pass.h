@@ -273,10 +273,14 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
 template <typename Policy, int BS, int K>
 __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n, PassArrays<float> A,
                                                        const int *__restrict__ cellStart,
+                                                       const int *__restrict__ sortedHash,
                                                        const unsigned short *__restrict__ list,
                                                        const unsigned short *__restrict__ counts, int xcd_log) {
-    __shared__ int rowStartG[16];  // 9 used
-    __shared__ int stagedFlag;
+    __shared__ int rowStartG[32];  // 9 used; up to kMaxSegs by a block with segments of its own
+    __shared__ int stagedFlag, sparseFlag;
+    __shared__ Segments sg;                          // (blocks with segments of their own only,
+    __shared__ int sparseTmp[20 * kSparseRuns + 16];  // see sparse_segments in fsa_tile.h)
+    static_assert(kMaxSegs <= 32, "segment table too small");
     if (P.halt && *P.halt) return;  // see DevParams::halt
     const int tid = threadIdx.x;
     const int b0 = xcd_block(xcd_log) * BS;
@@ -292,15 +296,23 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
     if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
     if (tid < 9) rowStartG[tid] = P.rows[(size_t)(b0 / BS) * kRowTableStride + tid];
     if (tid == 18) stagedFlag = P.rows[(size_t)(b0 / BS) * kRowTableStride + 18];
+    if (tid == 19) sparseFlag = P.rows[(size_t)(b0 / BS) * kRowTableStride + 19];
     __syncthreads();
     typename Policy::Self S;
     if (active) Policy::init(A, P, index, S);
     if (!stagedFlag) {
-        if (active) {
-            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
-            Policy::finish(A, P, index, S);
+        // a block whose list was built over segments of its own: the same segments, their starts in the table's place
+        bool sparse = false;
+        if (sparseFlag) sparse = sparse_segments<kRowCap>(P, b0, min(BS, n - b0), sortedHash, cellStart, sparseTmp, sg);
+        if (!sparse) {
+            if (active) {
+                generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+                Policy::finish(A, P, index, S);
+            }
+            return;
         }
-        return;
+        if (tid < sg.count) rowStartG[tid] = sg.start[tid];
+        __syncthreads();
     }
     const int bits = stagedFlag == 2 ? idx_bits<kRowCapBig>() : idx_bits<kRowCap>();  // as recorded for the block's class
     const unsigned mask = (1u << bits) - 1u;
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
         for (int u = 0; u < 4; u++) {
             // (the row look-up is unconditional -- slots past the end hold entry 0 -- so that the four LDS reads are
             // issued together and a select, not a branch, picks the lane's own index for an unused slot)
-            const int jr = rowStartG[(e[u] >> bits) & 15u] + (int)(e[u] & mask);  // (& 15: stale slots of the last word)
+            const int jr = rowStartG[(e[u] >> bits) & 31u] + (int)(e[u] & mask);  // (& 31: stale slots of the last word)
             B.j[u] = s + u < cnt ? jr : safe;
         }
 #pragma unroll
@@ -388,15 +400,19 @@ constexpr int kRowQuorum = 40;
 template <typename Policy, int BS, int ROWCAP, int K>
 __global__ __launch_bounds__(BS) void list_rows_kernel(DevParams<float> P, int n, PassArrays<float> A,
                                                        const int *__restrict__ cellStart,
+                                                       const int *__restrict__ sortedHash,
                                                        const unsigned short *__restrict__ list,
                                                        const unsigned short *__restrict__ counts, int xcd_log) {
     using Nb = typename Policy::Nb;
     constexpr bool kPos = !pos_in_nb<Policy>::value;  // positions in a tile of their own
     constexpr int kRegs = (ROWCAP + BS - 1) / BS;
-    __shared__ int rowStartG[16], rowLen[16];  // 9 used
-    __shared__ int stagedFlag;
+    __shared__ int rowStartG[32], rowLen[16];  // 9 used; rowStartG up to kMaxSegs by a block with segments of its own
+    __shared__ int stagedFlag, sparseFlag;
     __shared__ float4 tilePos[kPos ? 2 * ROWCAP : 1];
     __shared__ Nb tileNb[2 * ROWCAP];
+    static_assert(kMaxSegs <= 32, "segment table too small");
+    static_assert(sizeof(Nb) * 2 * ROWCAP >= sizeof(int) * (20 * kSparseRuns + 16) + sizeof(Segments) + 16,
+                  "the tile is the scratch space of sparse_segments");
     if (P.halt && *P.halt) return;  // see DevParams::halt
     const int tid = threadIdx.x;
     const int b0 = xcd_block(xcd_log) * BS;
@@ -413,16 +429,29 @@ __global__ __launch_bounds__(BS) void list_rows_kernel(DevParams<float> P, int n
     if (tid < 9) rowStartG[tid] = P.rows[(size_t)(b0 / BS) * kRowTableStride + tid];
     else if (tid < 18) rowLen[tid - 9] = P.rows[(size_t)(b0 / BS) * kRowTableStride + tid];
     else if (tid == 18) stagedFlag = P.rows[(size_t)(b0 / BS) * kRowTableStride + 18];
+    else if (tid == 19) sparseFlag = P.rows[(size_t)(b0 / BS) * kRowTableStride + 19];
     __syncthreads();
     typename Policy::Self S;
     if (active) Policy::init(A, P, index, S);
     const int cls = stagedFlag;
     if (cls == 0) {
-        if (active) {
-            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
-            Policy::finish(A, P, index, S);
+        // a block whose list was built over segments of its own (sparse_segments, fsa_tile.h; the tiles, which such a
+        // block does not use, lend the space): the same segments, their starts in the table's place, gathers
+        bool sparse = false;
+        if (sparseFlag) {
+            int *const tmp = reinterpret_cast<int *>(tileNb);
+            Segments &sg = *reinterpret_cast<Segments *>(tmp + 20 * kSparseRuns + 16);
+            sparse = sparse_segments<kRowCap>(P, b0, min(BS, n - b0), sortedHash, cellStart, tmp, sg);
+            if (sparse && tid < sg.count) rowStartG[tid] = sg.start[tid];
+            __syncthreads();
         }
-        return;
+        if (!sparse) {
+            if (active) {
+                generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+                Policy::finish(A, P, index, S);
+            }
+            return;
+        }
     }
     int cnt = active ? (int)counts[index] : 0;
     const bool overflow = cnt == kListOverflow;
@@ -437,16 +466,16 @@ __global__ __launch_bounds__(BS) void list_rows_kernel(DevParams<float> P, int n
             Policy::pair(A, P, S, j == index, tj, j, xx, xy, xz, d2, pj, nb);
         }
     };
-    if (cls == 2) {  // large tiles: gathers (entries carry 10 index bits)
-        constexpr int bits = idx_bits<kRowCapBig>();
-        constexpr unsigned mask = (1u << bits) - 1u;
+    if (cls != 1) {  // large tiles (entries carry 10 index bits) or segments of the block's own (9): gathers
+        const int bits = cls == 2 ? idx_bits<kRowCapBig>() : idx_bits<kRowCap>();
+        const unsigned mask = (1u << bits) - 1u;
         for (int s = 0; wave_any(s < cnt); s += 4) {
             const uint2 w = entries(s);
             const unsigned e[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (s + u < cnt) {
-                    const int j = rowStartG[(e[u] >> bits) & 15u] + (int)(e[u] & mask);
+                    const int j = rowStartG[(e[u] >> bits) & 31u] + (int)(e[u] & mask);
                     const Nb nb = Policy::load(A, j);
                     float4 pj;
                     if constexpr (kPos) pj = A.posType[j]; else pj = nb.pos();
@@ -621,10 +650,11 @@ template <typename Policy> static int run_tiled(Solver *s, const PassArrays<floa
     if (lists && s->use_lists && s->lists_valid) {
         if constexpr (row_replay<Policy>::value)
             hipLaunchKernelGGL((list_rows_kernel<Policy, kTunedBS, kRowCap, kListSlots>), dim3(nb), dim3(kTunedBS), 0,
-                               s->stream, s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, s->xcd_run_log);
+                               s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, s->b.nbList, s->b.nbCount,
+                               s->xcd_run_log);
         else
             hipLaunchKernelGGL((list_pass_kernel<Policy, kTunedBS, kListSlots>), dim3(nb), dim3(kTunedBS), 0, s->stream,
-                               s->pf, s->n, A, s->b.cellStart, s->b.nbList, s->b.nbCount, s->xcd_run_log);
+                               s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, s->b.nbList, s->b.nbCount, s->xcd_run_log);
     } else
     {
         hipLaunchKernelGGL((tuned_pass_kernel<Policy, kTunedBS, kRowCap, kQueueDf>), dim3(nb), dim3(kTunedBS), 0,
