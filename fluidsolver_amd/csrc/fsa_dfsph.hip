@@ -475,10 +475,7 @@ __global__ __launch_bounds__(kBlock) void block_max_kernel(int n, const T *__res
                                                            T *__restrict__ out) {
     __shared__ T part[kBlock / 64];
     T m = start;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const T v = in[i];
-        m = v > m ? v : m;
-    }
+    strided_fold(in, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, n, m, [](T &a, T v) { a = v > a ? v : a; });
     for (int d = 32; d >= 1; d >>= 1) {
         const T o = __shfl_xor(m, d, 64);
         m = o > m ? o : m;

@@ -629,7 +629,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void block_sum_kernel(int n, const T *__restrict__ in, double *__restrict__ out) {
     __shared__ double part[kBlock / 64];
     double acc = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) acc += (double)in[i];
+    strided_fold(in, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, n, acc, [](double &a, T v) { a += (double)v; });
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(kBlock) void halted_block_sum_kernel(int n, const T
     if (*halt) return;
     __shared__ double part[kBlock / 64];
     double acc = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) acc += (double)in[i];
+    strided_fold(in, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, n, acc, [](double &a, T v) { a += (double)v; });
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();

@@ -592,6 +592,22 @@ __global__ __launch_bounds__(BS) void list_rows_kernel(DevParams<float> P, int n
     if (active) Policy::finish(A, P, index, S);
 }
 
+// The elements i, i + stride, i + 2 stride, ... below n, folded into `acc` in that order -- eight loads in flight at a
+// time (one dependent load per trip reads at a quarter of the memory rate); the order, and so every bit of a
+// floating-point sum, is that of the plain loop.
+template <typename T, typename Acc, typename Fold>
+__device__ __forceinline__ void strided_fold(const T *__restrict__ in, int i, int stride, int n, Acc &acc, Fold fold) {
+    constexpr int kAhead = 8;
+    for (; (long long)i + (long long)(kAhead - 1) * stride < n; i += kAhead * stride) {
+        T v[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) v[u] = in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) fold(acc, v[u]);
+    }
+    for (; i < n; i += stride) fold(acc, in[i]);
+}
+
 static inline int blocks_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 #define DF_DISPATCH(kernel, ...)                                                                                  \
