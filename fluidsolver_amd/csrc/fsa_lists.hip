@@ -50,12 +50,7 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
             return;
         }
     } else {
-        if (tid < 9) {
-            sg.start[tid] = sh.rowStartG[tid];
-            sg.len[tid] = sh.rowLen[tid];
-            sg.row[tid] = tid;
-        }
-        if (tid == 9) sg.count = 9;
+        rows_as_segments(sh, sg);
         __syncthreads();
     }
     const int nseg = sg.count;
@@ -90,30 +85,17 @@ __global__ __launch_bounds__(BS) void list_build_kernel(DevParams<float> P, int 
         cnt = rem;
     };
 
-    // the lane's index range in tile k: its cells of that row, as far as the tile holds them
-    auto seg_range = [&](int k, int &a, int &b) {
-        a = b = 0;
-        if (active) {
-            const int row = sg.row[k];
-            const int c = walk.row_cell(P, row % 3 - 1, row / 3 - 1);
-            if (c >= 0) {
-                const int s0 = sg.start[k], len = sg.len[k];
-                a = min(max(cellStart[c] - s0, 0), len);
-                b = min(max(cellStart[c + (walk.xhi - walk.xlo) + 1] - s0, 0), len);
-            }
-        }
-    };
     float4 e[row_regs<BS, ROWCAP>()];
     int lj, le, nlj = 0, nle = 0;
     tile_fetch<BS, ROWCAP, false>(sg.start[0], sg.len[0], posType, e);
-    seg_range(0, lj, le);
+    segment_range(P, sg, walk, active, 0, cellStart, lj, le);
     row_store<BS, ROWCAP, false>(sh, 0, e);
     __syncthreads();
     for (int r = 0; r < nseg; r++) {
         const int buf = r & 1;
         if (r + 1 < nseg) {  // in flight during the cull below
             tile_fetch<BS, ROWCAP, false>(sg.start[r + 1], sg.len[r + 1], posType, e);
-            seg_range(r + 1, nlj, nle);
+            segment_range(P, sg, walk, active, r + 1, cellStart, nlj, nle);
         }
         const int tag = r << idx_bits<ROWCAP>();
         // One aligned group of four candidates; those with lo <= u < hi belong to the lane.

@@ -145,13 +145,27 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
     if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
     typename Policy::Self S;
     if (active) Policy::init(A, P, index, S);
+    // The tiles the cull walks: the block's nine rows, or, for a block whose particles lie in several stretches of
+    // cells (class 0 in the grid, fsa_tile.h), segments of its own; a queue entry is then segment << 9 | index.
+    __shared__ Segments sg;
     if (!staged) {
-        if (active) {
-            generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
-            Policy::finish(A, P, index, S);
+        bool sparse = false;
+        if constexpr (ROWCAP <= kRowCap) {
+            if (P.rows && P.rows[(size_t)blk * kRowTableStride + 19])
+                sparse = sparse_segments<ROWCAP>(P, b0, nb, sortedHash, cellStart, reinterpret_cast<int *>(sh.x), sg);
         }
-        return;
+        if (!sparse) {
+            if (active) {
+                generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+                Policy::finish(A, P, index, S);
+            }
+            return;
+        }
+    } else {
+        rows_as_segments(sh, sg);
+        __syncthreads();
     }
+    const int nseg = sg.count;
     const float sr = P.sr, sr2c = sr * sr * 1.000002f;
     const RowWalk<float> walk(P, pi.x, pi.y, pi.z);
     unsigned short *const q = queue + tid;
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
 #pragma unroll
         for (int u = 0; u < kDrainBatch; u++) {
             const int e = q[(s + u) * BS];
-            B.j[u] = s + u < cnt ? sh.rowStartG[e >> idx_bits<ROWCAP>()] + (e & ((1 << idx_bits<ROWCAP>()) - 1)) : safe;
+            B.j[u] = s + u < cnt ? sg.start[e >> idx_bits<ROWCAP>()] + (e & ((1 << idx_bits<ROWCAP>()) - 1)) : safe;
         }
 #pragma unroll
         for (int u = 0; u < kDrainBatch; u++) {
@@ -200,15 +214,15 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
 
     float4 e[row_regs<BS, ROWCAP>()];
     int lj, le, nlj = 0, nle = 0;
-    row_fetch<BS, ROWCAP, false>(sh, 0, A.posType, e);
-    lane_range(P, sh, walk, active, 0, cellStart, lj, le);
+    tile_fetch<BS, ROWCAP, false>(sg.start[0], sg.len[0], A.posType, e);
+    segment_range(P, sg, walk, active, 0, cellStart, lj, le);
     row_store<BS, ROWCAP, true>(sh, 0, e);
     __syncthreads();
-    for (int r = 0; r < 9; r++) {
+    for (int r = 0; r < nseg; r++) {
         const int buf = r & 1;
-        if (r + 1 < 9) {
-            row_fetch<BS, ROWCAP, false>(sh, r + 1, A.posType, e);
-            lane_range(P, sh, walk, active, r + 1, cellStart, nlj, nle);
+        if (r + 1 < nseg) {
+            tile_fetch<BS, ROWCAP, false>(sg.start[r + 1], sg.len[r + 1], A.posType, e);
+            segment_range(P, sg, walk, active, r + 1, cellStart, nlj, nle);
         }
         const int tag = r << idx_bits<ROWCAP>();
         auto cull_group = [&](int g, int lo, int hi, auto masked_tag) {
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
             cull_group(rem > 0 ? base / kChunk : Shared::kPad, 0, rem, std::true_type());
             if (wave_any(cnt > Q - kChunk)) drain();
         }
-        if (r + 1 < 9) {
+        if (r + 1 < nseg) {
             row_store<BS, ROWCAP, true>(sh, buf ^ 1, e);
             lj = nlj;
             le = nle;

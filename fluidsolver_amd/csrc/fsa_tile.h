@@ -327,6 +327,34 @@ __device__ __forceinline__ bool sparse_segments(const DevParams<float> &P, int b
     return total != 0;
 }
 
+// The nine rows of a staged block as nine segments (visible after the next barrier).
+template <typename Shared> __device__ __forceinline__ void rows_as_segments(const Shared &sh, Segments &sg) {
+    const int tid = threadIdx.x;
+    if (tid < 9) {
+        sg.start[tid] = sh.rowStartG[tid];
+        sg.len[tid] = sh.rowLen[tid];
+        sg.row[tid] = tid;
+    }
+    if (tid == 9) sg.count = 9;
+}
+
+// The lane's index range in segment k, relative to the segment's first particle: the cells of that row next to the
+// lane's own, as far as the segment holds them (two loads of the cell table).
+__device__ __forceinline__ void segment_range(const DevParams<float> &P, const Segments &sg, const RowWalk<float> &walk,
+                                              bool active, int k, const int *__restrict__ cellStart, int &lj, int &le) {
+    lj = 0;
+    le = 0;
+    if (active) {
+        const int row = sg.row[k];
+        const int c = walk.row_cell(P, row % 3 - 1, row / 3 - 1);
+        if (c >= 0) {
+            const int s0 = sg.start[k], len = sg.len[k];
+            lj = min(max(cellStart[c] - s0, 0), len);
+            le = min(max(cellStart[c + (walk.xhi - walk.xlo) + 1] - s0, 0), len);
+        }
+    }
+}
+
 // The lane's index range in row r, relative to the row's first particle (two loads of the cell table).
 template <typename Shared>
 __device__ __forceinline__ void lane_range(const DevParams<float> &P, const Shared &sh, const RowWalk<float> &walk,
