@@ -246,7 +246,7 @@ __device__ __forceinline__ bool sparse_segments(const DevParams<float> &P, int b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *const lo = scratch, *const hi = lo + kSparseRuns;  // cell of the first / last particle of each run
     int *const A = hi + kSparseRuns, *const B = A + 9 * kSparseRuns;  // [run][row]: the range a run needs of a row
-    int *const misc = B + 9 * kSparseRuns;  // [0..8] segments per row, then their prefix; [9] verdict; [10..13] heads per wavefront
+    int *const misc = B + 9 * kSparseRuns;  // [0..8] segments per row, then their prefix; [9] number of segments, 0 = give up; [10..13] heads per wavefront
     const bool in = tid < nb;
     const int h = in ? sortedHash[b0 + tid] : 0;
     const bool head = in && (tid == 0 || h - sortedHash[b0 + tid - 1] > 2);
