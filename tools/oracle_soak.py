@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""fsa_step on the exact-arithmetic kernels (variant 1) beside the CPU oracle on the same dam break, compared every
+--every steps: order of the particles and every bit of pos / vel / density / pressure / force (fluid)."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fluidsolver_amd import capi, scenes
+from oracle.orc import Oracle
+from util import gpu_solver, oracle_pair
+ap = argparse.ArgumentParser()
+ap.add_argument("--dims", type=int, nargs=3, default=[128, 64, 128])
+ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--every", type=int, default=50)
+ap.add_argument("--variant", type=int, default=1)
+a = ap.parse_args()
+sc = scenes.dam_break(*a.dims)
+orc = Oracle("f32")
+orc.set_threads(min(16, os.cpu_count() or 1))
+p_o, st = oracle_pair(orc, sc)
+p_g, s = gpu_solver(sc)
+s.set_variant(a.variant)
+log, t_cpu = [], 0.0
+for done in range(a.every, a.steps + 1, a.every):
+    t0 = time.perf_counter(); st.solve_sph(p_o, a.every); t_cpu += time.perf_counter() - t0
+    s.step(a.every)
+    fl = st["type"] == 0
+    bad = [] if np.array_equal(s.get("uniqueId"), st["uniqueId"]) else ["order"]
+    if not bad:
+        bad = [k for k in ("pos", "vel", "density", "pressure") if s.get(k).tobytes() != np.ascontiguousarray(st[k], np.float32).tobytes()]
+        if s.get("force")[fl].tobytes() != np.ascontiguousarray(st["force"], np.float32)[fl].tobytes():
+            bad.append("force")
+    v = np.linalg.norm(st["vel"][fl], axis=1).max()
+    log.append({"step": done, "differs": bad, "max_speed": float(v), "out_of_grid": s.num_undef()})
+    print(json.dumps(log[-1]), file=sys.stderr, flush=True)
+    if bad:
+        break
+print(json.dumps({"dims": a.dims, "particles": len(sc["pos"]), "variant": a.variant, "steps": log[-1]["step"],
+                  "equal_bit_for_bit": not log[-1]["differs"], "oracle_seconds": round(t_cpu, 1), "log": log}))
