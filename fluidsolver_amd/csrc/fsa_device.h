@@ -85,6 +85,16 @@ __device__ __forceinline__ float r_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double r_floor(double x) { return floor(x); }
 __device__ __forceinline__ float r_pow(float x, float y) { return powf(x, y); }
 __device__ __forceinline__ double r_pow(double x, double y) { return pow(x, y); }
+// x^7 of the pressure equation (powf(density / restDensity, 7), solver/sph_kernel_impl.cuh:263).  No powf is correctly
+// rounded everywhere and no two libraries agree on every argument (ROCm's differs from the correctly rounded value
+// in the last bit for about one argument in a thousand); the fp32 solvers take the product in double, four roundings
+// of 2^-53, and round once to float: the correctly rounded power but for ties closer than that, and cheaper than powf.
+// Same special cases (odd power keeps the sign, NaN and infinities pass through, overflow gives infinity).
+__device__ __forceinline__ float r_pow7(float x) {
+    const double d = (double)x, d2 = d * d, d4 = d2 * d2;
+    return (float)(d4 * d2 * d);
+}
+__device__ __forceinline__ double r_pow7(double x) { return pow(x, 7.0); }
 
 // float -> int, saturating, NaN -> 0 (what cvt.rzi.s32.f32 gives the reference)
 template <typename T> __device__ __forceinline__ int to_int_sat(T v) {

@@ -397,7 +397,7 @@ template <typename T> struct DensityRigidPolicy {
     }
     static __device__ __forceinline__ void finish(const PassArrays<T> &A, const DevParams<T> &P, int index, Self &S) {
         A.densityOut[index] = S.dens;
-        T pr = P.pressureK * (r_pow(S.dens / S.rd, (T)7) - 1);
+        T pr = P.pressureK * (r_pow7(S.dens / S.rd) - 1);
         if (pr < 0) pr = 0;
         A.pstiffOut[index] = pr;  // the launcher points this at the pressure array
     }

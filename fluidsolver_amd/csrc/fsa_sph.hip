@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kBlock) void density_kernel(DevParams<T> P, int n,
     const T rd_i = restDensity[index];
     const T dens = density_walk_global(P, index, pi, velMass[index].w, rd_i, posType, restDensity, cellStart);
     density[index] = dens;
-    T pr = P.pressureK * (r_pow(dens / rd_i, (T)7) - 1);
+    T pr = P.pressureK * (r_pow7(dens / rd_i) - 1);
     if (pr < 0) pr = 0;
     pressure[index] = pr;
 }

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
         wallCount[index] = (unsigned char)wwords;
         if (EVAL) {
             density[index] = dens;
-            float pr = P.pressureK * (r_pow(dens / rd_i, 7.0f) - 1);
+            float pr = P.pressureK * (r_pow7(dens / rd_i) - 1);
             if (pr < 0) pr = 0;
             pressure[index] = pr;
             // the per-particle terms of the force pass, while they are at hand

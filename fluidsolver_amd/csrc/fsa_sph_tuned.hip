@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BS) void density_tuned_kernel(DevParams<float> P, i
     }
     if (active) {
         density[index] = dens;
-        float pr = P.pressureK * (r_pow(dens / rd_i, 7.0f) - 1);
+        float pr = P.pressureK * (r_pow7(dens / rd_i) - 1);
         if (pr < 0) pr = 0;
         pressure[index] = pr;
         // the per-particle terms of the force pass (what force_prep_kernel computes), while they are at hand

@@ -133,24 +133,25 @@ def test_one_step_at_one_million_particles(orc32):
     st.close()
 
 
-def test_twenty_steps_at_one_million_particles_bit_for_bit(orc32):
-    """BASELINE's 1 M dam break stepped 20 times by fsa_step on the exact-arithmetic kernels (variant 1: the tiled
+def test_sixty_steps_at_one_million_particles_bit_for_bit(orc32):
+    """BASELINE's 1 M dam break stepped 60 times by fsa_step on the exact-arithmetic kernels (variant 1: the tiled
     structure, the reference's expression order) and by the oracle: the same order of particles and the same bits in
-    every array, i.e. no sum in 20 x 1.26 M neighbourhoods differs by a rounding.  Twenty steps, because the lattice
-    is still falling then: from the step the fluid is first compressed (between 30 and 40, tools/oracle_soak.py) the
-    pressure equation's powf(rho / rho0, 7) is no longer clamped to zero, and ROCm's powf and glibc's (and CUDA's, in
-    the reference: solver/sph_kernel_impl.cuh:263) are three implementations that differ in the last bit for some
-    arguments; from there on the stage-by-stage bars of the tests above apply, as they do to the default fast
-    flavour throughout."""
+    every array, i.e. no sum in 60 x 1.26 M neighbourhoods differs by a rounding (by step 60 the fluid has hit the
+    floor and 140 000 particles have a pressure).  tools/oracle_soak.py carries the comparison on through the
+    collapse: equal after 1000 steps.  What makes this possible is that both sides take the seventh power of the
+    pressure equation as a product in double rounded once (r_pow7 / orc_pow7f): with each side's library powf the
+    runs part when the first pressures appear, between steps 30 and 40.  (The default fast flavour is held to the
+    per-element bars of the tests above.)"""
     sc = scenes.dam_break(128, 64, 128)
     p_o, st = oracle_pair(orc32, sc)
     p_g, s = gpu_solver(sc)
     s.set_variant(1)
-    st.solve_sph(p_o, 20)
-    s.step(20)
+    st.solve_sph(p_o, 60)
+    s.step(60)
     assert np.array_equal(s.get("uniqueId"), st["uniqueId"])
     for k in ("pos", "vel", "density", "pressure"):
         assert s.get(k).tobytes() == np.ascontiguousarray(st[k], np.float32).tobytes(), k
+    assert (st["pressure"] > 0).sum() > 100000
     fl = st["type"] == 0  # (force[] of other types is never written by either side)
     assert s.get("force")[fl].tobytes() == np.ascontiguousarray(st["force"], np.float32)[fl].tobytes()
     s.close()
