@@ -94,7 +94,12 @@ __device__ __forceinline__ float r_pow7(float x) {
     const double d = (double)x, d2 = d * d, d4 = d2 * d2;
     return (float)(d4 * d2 * d);
 }
-__device__ __forceinline__ double r_pow7(double x) { return pow(x, 7.0); }
+// (fp64 solvers, which the reference does not have: the same product, so that a run can be compared with the fp64
+// oracle's bit for bit; within four roundings of 2^-53 of pow(x, 7.0))
+__device__ __forceinline__ double r_pow7(double x) {
+    const double d2 = x * x, d4 = d2 * d2;
+    return d4 * d2 * x;
+}
 
 // float -> int, saturating, NaN -> 0 (what cvt.rzi.s32.f32 gives the reference)
 template <typename T> __device__ __forceinline__ int to_int_sat(T v) {

@@ -23,7 +23,13 @@ typedef ORC_NAME(state) state_t;
 #define R_SQRT(x) sqrt(x)
 #define R_FLOOR(x) floor(x)
 #define R_POW(x, y) pow((x), (y))
-#define R_POW7(x) pow((x), 7.0)
+/* (the fp64 build, which has no counterpart in the reference: the product the fp64 HIP kernels take, see orc_pow7f
+ * below; within four roundings of 2^-53 of pow(x, 7.0)) */
+static inline double orc_pow7d(double x) {
+    const double d2 = x * x, d4 = d2 * d2;
+    return d4 * d2 * x;
+}
+#define R_POW7(x) orc_pow7d(x)
 #define R_ROUND(x) round(x)
 #else
 #define R_SQRT(x) sqrtf(x)

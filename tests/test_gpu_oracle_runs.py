@@ -28,11 +28,17 @@ def scene_for(step):
 
 @pytest.mark.parametrize("step,steps,every", [("wcsph", 400, 100), ("ddam", 300, 100), ("dfsph", 150, 50),
                                               ("iisph", 150, 50)])
-def test_run_equals_the_oracle_bit_for_bit(orc32, step, steps, every):
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_run_equals_the_oracle_bit_for_bit(orc32, orc64, precision, step, steps, every):
+    """f64: the fp64 solvers (generic kernels; the reference has no fp64 path) against the fp64 build of the oracle --
+    the criterion there is 1e-10, what is measured is equality"""
     sc = scene_for(step)
-    p_o, st = oracle_pair(orc32, sc)
-    p_g, s = gpu_solver(sc)
-    s.set_variant(1)
+    f64 = precision == "f64"
+    real = np.float64 if f64 else np.float32
+    p_o, st = oracle_pair(orc64 if f64 else orc32, sc)
+    p_g, s = gpu_solver(sc, 1 if f64 else 0)
+    if not f64:
+        s.set_variant(1)
     if step == "dfsph":
         st.sort_particles(p_o)
         st.compute_density_alpha(p_o)
@@ -52,10 +58,10 @@ def test_run_equals_the_oracle_bit_for_bit(orc32, step, steps, every):
             s.step_iisph(every)
         assert np.array_equal(s.get("uniqueId"), st["uniqueId"]), (step, done)
         for k in ("pos", "vel", "density", "pressure"):
-            assert s.get(k).tobytes() == np.ascontiguousarray(st[k], np.float32).tobytes(), (step, done, k)
+            assert s.get(k).tobytes() == np.ascontiguousarray(st[k], real).tobytes(), (step, done, k)
         fl = st["type"] == 0
         if step in ("wcsph", "ddam"):  # (force[] of other types is never written by either side)
-            assert s.get("force")[fl].tobytes() == np.ascontiguousarray(st["force"], np.float32)[fl].tobytes(), (step, done)
+            assert s.get("force")[fl].tobytes() == np.ascontiguousarray(st["force"], real)[fl].tobytes(), (step, done)
         moved = max(moved, float(np.linalg.norm(st["vel"][fl], axis=1).max()))
     assert moved > 0.3, "the flow was meant to develop"
     s.close()

@@ -16,6 +16,7 @@ ap.add_argument("--dims", type=int, nargs=3, default=[128, 64, 128])
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--every", type=int, default=50)
 ap.add_argument("--variant", type=int, default=1)
+ap.add_argument("--f64", action="store_true", help="the fp64 solver (generic kernels) beside the fp64 oracle")
 ap.add_argument("--step", choices=["wcsph", "dfsph", "iisph"], default="wcsph")
 ap.add_argument("--scene", choices=["dam", "ddam"], default="dam", help="dam break, or double dam break with obstacles")
 a = ap.parse_args()
@@ -27,11 +28,13 @@ if a.step == "iisph":
     sc["params"] = dict(sc["params"], viscosity=0.05, **scenes.IISPH_PARAMS)
 else:
     sc = scenes.dam_break(*a.dims) if a.scene == "dam" else scenes.double_dam_break(*a.dims)
-orc = Oracle("f32")
+orc = Oracle("f64" if a.f64 else "f32")
 orc.set_threads(min(16, os.cpu_count() or 1))
 p_o, st = oracle_pair(orc, sc)
-p_g, s = gpu_solver(sc)
-s.set_variant(a.variant)
+p_g, s = gpu_solver(sc, 1 if a.f64 else 0)
+if not a.f64:
+    s.set_variant(a.variant)
+real = np.float64 if a.f64 else np.float32
 if a.step == "dfsph":
     st.sort_particles(p_o); st.compute_density_alpha(p_o)
     s.setup_dfsph()
@@ -59,13 +62,13 @@ for done in range(a.every, a.steps + 1, a.every):
     fl = st["type"] == 0
     bad = [] if np.array_equal(s.get("uniqueId"), st["uniqueId"]) else ["order"]
     if not bad:
-        bad = [k for k in ("pos", "vel", "density", "pressure") if s.get(k).tobytes() != np.ascontiguousarray(st[k], np.float32).tobytes()]
-        if a.step == "wcsph" and s.get("force")[fl].tobytes() != np.ascontiguousarray(st["force"], np.float32)[fl].tobytes():
+        bad = [k for k in ("pos", "vel", "density", "pressure") if s.get(k).tobytes() != np.ascontiguousarray(st[k], real).tobytes()]
+        if a.step == "wcsph" and s.get("force")[fl].tobytes() != np.ascontiguousarray(st["force"], real)[fl].tobytes():
             bad.append("force")
     v = np.linalg.norm(st["vel"][fl], axis=1).max()
     log.append({"step": done, "differs": bad, "max_speed": float(v), "out_of_grid": s.num_undef()})
     print(json.dumps(log[-1]), file=sys.stderr, flush=True)
     if bad:
         break
-print(json.dumps({"step": a.step, "scene": a.scene, "dims": a.dims, "particles": len(sc["pos"]), "variant": a.variant, "steps": log[-1]["step"],
+print(json.dumps({"step": a.step, "scene": a.scene, "dims": a.dims, "particles": len(sc["pos"]), "variant": a.variant, "f64": a.f64, "steps": log[-1]["step"],
                   "equal_bit_for_bit": not log[-1]["differs"], "oracle_seconds": round(t_cpu, 1), "log": log}))
