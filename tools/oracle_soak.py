@@ -16,6 +16,8 @@ ap.add_argument("--dims", type=int, nargs=3, default=[128, 64, 128])
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--every", type=int, default=50)
 ap.add_argument("--variant", type=int, default=1)
+ap.add_argument("--jitter", type=float, default=0.0, help="noise on the fluid particles' start positions, in spacings (and on their velocities)")
+ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--f64", action="store_true", help="the fp64 solver (generic kernels) beside the fp64 oracle")
 ap.add_argument("--step", choices=["wcsph", "dfsph", "iisph"], default="wcsph")
 ap.add_argument("--scene", choices=["dam", "ddam"], default="dam", help="dam break, or double dam break with obstacles")
@@ -28,6 +30,8 @@ if a.step == "iisph":
     sc["params"] = dict(sc["params"], viscosity=0.05, **scenes.IISPH_PARAMS)
 else:
     sc = scenes.dam_break(*a.dims) if a.scene == "dam" else scenes.double_dam_break(*a.dims)
+if a.jitter > 0:
+    sc = scenes.jittered(sc, seed=a.seed, pos_jitter=a.jitter, vel_scale=0.5, fluid_only=True)
 orc = Oracle("f64" if a.f64 else "f32")
 orc.set_threads(min(16, os.cpu_count() or 1))
 p_o, st = oracle_pair(orc, sc)
@@ -70,5 +74,5 @@ for done in range(a.every, a.steps + 1, a.every):
     print(json.dumps(log[-1]), file=sys.stderr, flush=True)
     if bad:
         break
-print(json.dumps({"step": a.step, "scene": a.scene, "dims": a.dims, "particles": len(sc["pos"]), "variant": a.variant, "f64": a.f64, "steps": log[-1]["step"],
+print(json.dumps({"step": a.step, "scene": a.scene, "dims": a.dims, "particles": len(sc["pos"]), "variant": a.variant, "f64": a.f64, "jitter": a.jitter, "seed": a.seed, "steps": log[-1]["step"],
                   "equal_bit_for_bit": not log[-1]["differs"], "oracle_seconds": round(t_cpu, 1), "log": log}))
