@@ -254,8 +254,10 @@ __device__ __forceinline__ bool sparse_segments(const DevParams<float> &P, int b
     const unsigned long long hb = __ballot(head);
     if (lane == 0) misc[10 + wave] = __popcll(hb);
     __syncthreads();
-    int before = 0, nruns = 0;  // (256 threads: four wavefronts)
-    for (int w = 0; w < 4; w++) {
+    static_assert(kTunedBS % 64 == 0 && kTunedBS / 64 <= 4 && 9 * kSparseRuns <= kTunedBS,
+                  "sparse_segments is written for the workgroups of the tiled kernels (kTunedBS threads)");
+    int before = 0, nruns = 0;
+    for (int w = 0; w < kTunedBS / 64; w++) {
         before += w < wave ? misc[10 + w] : 0;
         nruns += misc[10 + w];
     }
