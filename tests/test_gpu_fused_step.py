@@ -159,3 +159,22 @@ def test_blocks_with_stretches_of_cells_are_tiled():
         # shows as more of the net force: the bar of tests/test_gpu_developed.py)
         assert force_err(out[2][1][fluid], out[0][1][fluid]) <= 1e-4
     s.close()
+
+
+def test_variant_3_tracks_variant_2_through_a_developing_flow():
+    """the one-search step (recorded hits, segments) beside the step whose two passes both search and whose untileable
+    blocks walk the cells: the same bits in every array every 100 steps of a dam break that collapses and splashes
+    (tools/variant_soak.py runs this at 1 M particles for 3000 steps)"""
+    sc = scenes.jittered(scenes.dam_break(48, 24, 32), seed=11, pos_jitter=0.3, vel_scale=0.5, fluid_only=True)
+    _, a = gpu_solver(sc)
+    _, b = gpu_solver(sc)
+    a.set_variant(3)
+    b.set_variant(2)
+    for done in range(100, 601, 100):
+        a.step(100)
+        b.step(100)
+        same(snapshot(a), snapshot(b))
+    fluid = a.get("type") == 0
+    assert np.linalg.norm(a.get("vel")[fluid], axis=1).max() > 0.5
+    a.close()
+    b.close()
