@@ -188,6 +188,8 @@ def load() -> C.CDLL:
     for name in ("fsa_debug_host_waits", "fsa_debug_event_waits"):  # not in the public header
         getattr(lib, name).restype = C.c_longlong
         getattr(lib, name).argtypes = []
+    lib.fsa_debug_one_mass_flavour.restype = C.c_int
+    lib.fsa_debug_one_mass_flavour.argtypes = [H]
     _lib = lib
     return lib
 

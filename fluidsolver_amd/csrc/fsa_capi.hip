@@ -726,7 +726,6 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
     }
     if (k == "type" || k == "mass") {
         TRY(want(k == "type" ? N * sizeof(int) : N * R));
-        s->fluid_mass_uniform = false;  // (not looked at again: the general kernels serve)
         Staging st;
         TRY(st.alloc(bytes));
         TRY(launch_unpack_w(s, k == "type" ? s->b.posType[c] : s->b.velMass[c], st.d, s->n, k == "type"));
@@ -885,6 +884,9 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
         Staging st;
         TRY(st.alloc(bytes));
         if (bytes) FSA_HIP(hipMemcpy(st.d, src, bytes, hipMemcpyHostToDevice));
+        // the one-mass flavour of applyPStiff holds only for the masses and types handed over by fsa_upload: any
+        // later change of either goes back to the general kernels (not looked at again)
+        s->fluid_mass_uniform = false;
         if (k == "type") {
             s->has_rigid = false;
             for (size_t i = 0; i < N; i++)
@@ -1251,6 +1253,12 @@ int fsa_set_scene_has_rigid(fsa_solver *hs, int has_rigid) {
 long long fsa_debug_host_waits(void) { return g_host_waits.load(); }
 // ... and how often it has waited for an event recorded some steps earlier (the device was not idle meanwhile)
 long long fsa_debug_event_waits(void) { return g_event_waits.load(); }
+
+// 1 when applyPStiff would take the one-mass flavour on this solver's present state (tests)
+int fsa_debug_one_mass_flavour(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    return s && s->fluid_mass_uniform ? 1 : 0;
+}
 
 // Not part of the public header: kernel-ablation timing used by tools/ablate.py.
 int fsa_debug_time_pass(fsa_solver *hs, int which, int ablate, int reps) {

@@ -166,6 +166,10 @@ def test_correction_loops_equal_their_stage_calls_bit_for_bit(name):
     b.close()
 
 
+def one_mass_flavour(s):
+    return capi.load().fsa_debug_one_mass_flavour(s._h)
+
+
 def test_one_mass_for_all_fluid_flavour_of_apply_pstiff_gives_the_same_bits():
     """with one mass for every fluid particle applyPStiff reads a single packed record per neighbour; handing the
     same masses over again with set() switches that off: both ways must agree bit for bit"""
@@ -173,6 +177,9 @@ def test_one_mass_for_all_fluid_flavour_of_apply_pstiff_gives_the_same_bits():
     _, a = gpu_solver(sc)
     _, b = gpu_solver(sc)
     b.set("mass", np.asarray(sc["mass"], np.float32))
+    assert one_mass_flavour(a) == 1 and one_mass_flavour(b) == 0
+    a.get("mass"), a.get("type")   # reading must not change which kernels run
+    assert one_mass_flavour(a) == 1
     for s in (a, b):
         s.setup_dfsph()
         s.step_dfsph(3)
@@ -180,6 +187,47 @@ def test_one_mass_for_all_fluid_flavour_of_apply_pstiff_gives_the_same_bits():
         assert a.get(k).tobytes() == b.get(k).tobytes(), k
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("what", ["mass", "type"])
+def test_masses_or_types_set_after_a_one_mass_upload_reach_apply_pstiff(what, orc32):
+    """upload one mass for all fluid particles, then hand over varied masses (or turn wall particles into fluid ones
+    of another mass) with set(): applyPStiff must read the neighbours' masses again, as the oracle does"""
+    sc = scene("compressed")
+    rng = np.random.Generator(np.random.PCG64(29))
+    sc2 = dict(sc)
+    if what == "mass":
+        sc2["mass"] = (np.asarray(sc["mass"]) * rng.uniform(0.9, 1.1, len(sc["mass"]))).astype(np.float32)
+    else:
+        t = np.array(sc["type"])
+        walls = np.flatnonzero(t != 0)
+        assert len(walls) and not np.all(np.asarray(sc["mass"])[walls] == np.asarray(sc["mass"])[t == 0][0])
+        t[walls[::3]] = 0
+        sc2["type"] = t
+    p_o, st = oracle_pair(orc32, sc2)
+    _, s = gpu_solver(sc)
+    assert one_mass_flavour(s) == 1
+    s.set(what, np.asarray(sc2[what]))
+    assert one_mass_flavour(s) == 0
+    _, ref = gpu_solver(sc2)           # the same scene uploaded as it is: the general kernels from the start
+    assert one_mass_flavour(ref) == 0
+    st.sort_particles(p_o)
+    st.compute_density_alpha(p_o)
+    st.compute_non_pressure_force(p_o)
+    st.solve_density_stiff(p_o)
+    st.apply_pstiff(p_o)
+    for g in (s, ref):
+        g.sort_particles()
+        g.compute_density_alpha()
+        g.compute_non_pressure_force()
+        g.solve_density_stiff()
+        g.apply_pstiff()
+    assert np.array_equal(s.get("uniqueId"), st["uniqueId"])
+    assert s.get("v_star").tobytes() == ref.get("v_star").tobytes()
+    assert rel_err(s.get("v_star"), st["v_star"]) <= 2e-5
+    s.close()
+    ref.close()
+    st.close()
 
 
 def test_five_dfsph_steps(pair):
