@@ -47,6 +47,13 @@ static inline float orc_pow7f(float x) {
 }
 #define R_POW7(x) orc_pow7f(x)
 #define R_ROUND(x) roundf(x)
+/* for the tests: the seventh power as the pressure equation takes it, beside this host's powf(x, 7) */
+void orc_pow7_probe(const float *x, int n, float *product, float *libm) {
+    for (int i = 0; i < n; i++) {
+        product[i] = orc_pow7f(x[i]);
+        libm[i] = powf(x[i], 7);
+    }
+}
 #endif
 
 static int g_threads = 1;

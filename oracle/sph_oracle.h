@@ -100,6 +100,12 @@ typedef struct ORC_NAME(state) {
     orc_real *aii, *density_star;           /* IISPH, n each */
 } ORC_NAME(state);
 
+#ifndef ORC_REAL_IS_DOUBLE
+/* tests only: the seventh power of the pressure equation as the oracle takes it (product in double, rounded once)
+ * beside this host's powf(x, 7) */
+void orc_pow7_probe(const float *x, int n, float *product, float *libm);
+#endif
+
 ORC_NAME(state) *ORC_NAME(create)(int n, int num_cells);
 void ORC_NAME(destroy)(ORC_NAME(state) *s);
 
