@@ -38,6 +38,16 @@ ALGO_BYTES = {
 }
 
 
+VARIANT_NAMES = {
+    0: "0: one thread per particle, the reference's expression order and double promotions",
+    1: "1: LDS-tiled kernels, exact arithmetic (bit-equal to the CPU oracle over whole runs)",
+    2: "2: LDS-tiled kernels, fast fp32 pair arithmetic (within 1e-5 per element of the oracle)",
+    3: "3: as 2 with one neighbour search per step (record / replay); bit-equal to 2, within 1e-5 per element of "
+       "the oracle",
+}
+DEVELOPED_FLOW_STEPS = int(os.environ.get("FSA_BENCH_FLOW_STEPS", 2000))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +66,7 @@ def parse():
     return ap.parse_args()
 
 
-SCENES = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64), "ddam64m": (320, 320, 320)}
+SCENES = {"dam16m": (256, 256, 256), "dam16m_flat": (512, 64, 512), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64), "ddam64m": (320, 320, 320)}
 
 
 def build_scene(name, jitter=0.0, z_select=None):
@@ -123,20 +133,21 @@ def cpu_baseline(sc, scene_name):
                               "sample": f"1M-particle dam break ({n1} particles), {s1} steps, {d1:.1f} s"}}
 
 
-def run_single(args, jitter=None, keep_scene=False):
+def run_single(args, jitter=None, keep_scene=False, variant=None, spinup=None, record_stats=False, scene=None):
     import torch
     from fluidsolver_amd import capi
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(0)
-    sc = build_scene(args.scene, args.jitter if jitter is None else jitter)
+    sc = build_scene(scene or args.scene, args.jitter if jitter is None else jitter)
     n, n_fluid = len(sc["pos"]), sc["n_fluid"]
     p = capi.make_params(capi.PRECISION_F32, **sc["params"])
     s = capi.Solver(p, n)
-    if args.variant is not None:
-        s.set_variant(args.variant)
+    variant = args.variant if variant is None else variant
+    if variant is not None:
+        s.set_variant(variant)
     s.upload(sc)
-    s.step(args.spinup)
+    s.step(args.spinup if spinup is None else spinup)
     s.step(args.warmup)
     s.synchronize()
     s.timing_enable(True)
@@ -150,9 +161,19 @@ def run_single(args, jitter=None, keep_scene=False):
     kt = s.timing_read()
     s.timing_enable(False)
     n_undef = s.num_undef() if args.steps + args.warmup + args.spinup > 0 else 0
+    stats = None
+    if record_stats:  # how many fluid particles the last step's record kernels could not serve from the tiles
+        s.sort_particles()
+        s.compute_pressure()
+        fluid = s.get("type") == 0
+        hc = s.get("hitCount")
+        stats = {"fluid_particles_without_record": int(((hc < 0) & fluid).sum()),
+                 "fraction_without_record": float(((hc < 0) & fluid).sum() / max(int(fluid.sum()), 1)),
+                 "max_speed": float(np.linalg.norm(s.get("vel")[fluid], axis=1).max())}
     s.close()
     return dict(n=n, n_fluid=n_fluid, wall=wall, kernels=kt, num_cells=p.num_cells, n_undef=n_undef,
-                gridres=list(p.gridres), scene=sc if keep_scene else None)
+                gridres=list(p.gridres), scene=sc if keep_scene else None, stats=stats,
+                variant=3 if variant is None else variant)
 
 
 def main():
@@ -225,6 +246,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"dam16m": "dam break, 256^3 = 16 777 216 fluid particles + one layer of wall "
                                           "particles, WCSPH fp32, shipped SceneId-2 parameters (viscosity 0.01)",
+                                "dam16m_flat": "dam break 512x64x512 = 16 777 216 fluid particles, column 0.32 m high",
                                 "dam1m": "dam break 128x64x128 = 1 048 576 fluid particles",
                                 "dam128k": "dam break 64x32x64 fluid particles",
                                 "ddam64m": "double dam break, 2 x 320^3 = 65 536 000 fluid particles, box obstacles, "
@@ -232,6 +254,7 @@ def main():
                    "particles_total": res["n"], "particles_counted": res["n_fluid"], "grid": res["gridres"],
                    "spinup_steps": args.spinup, "parallelism": f"z-slabs x{args.gpus}" if args.gpus > 1 else "1 GPU",
                    "out_of_grid_particles": res["n_undef"],
+                   "kernel_variant": VARIANT_NAMES.get(res.get("variant", 3 if args.variant is None else args.variant)),
                    **{k: res[k] for k in ("comm_backend", "slab_step", "slab_cuts", "halo_layers",
                                           "max_local_particles", "mean_local_particles", "lost_particles",
                                           "records_sent_per_step", "exchange_ms_per_step_max",
@@ -250,6 +273,35 @@ def main():
             "ms_per_step": dev["wall"] / steps * 1e3, "value": dev["n_fluid"] * steps / dev["wall"],
             "unit": "particle-steps/s",
             "kernels_ms": {k: (ms / c if c else 0.0) for k, (c, ms) in dev["kernels"].items()}}
+        # ... and the flow itself: the column after DEVELOPED_FLOW_STEPS steps of collapse
+        flow = run_single(args, spinup=DEVELOPED_FLOW_STEPS, record_stats=True)
+        out["config"]["developed_flow"] = {
+            "state": f"same scene after {DEVELOPED_FLOW_STEPS} steps of collapse "
+                     f"({DEVELOPED_FLOW_STEPS * 4e-4:.2f} s of flow)",
+            "ms_per_step": flow["wall"] / steps * 1e3, "value": flow["n_fluid"] * steps / flow["wall"],
+            "unit": "particle-steps/s", "out_of_grid_particles": flow["n_undef"], **flow["stats"],
+            "kernels_ms": {k: (ms / c if c else 0.0) for k, (c, ms) in flow["kernels"].items()}}
+        if args.scene == "dam16m":
+            # The 1.28 m column of the headline scene is far outside what the shipped stiffness and one layer of
+            # penalty wall particles hold: the bottom compresses by 40 % and from step 400 on fluid is pressed
+            # through the floor onto the grid-box clamp (out_of_grid_particles above).  The same number of
+            # particles as a column 0.32 m high (BASELINE config 2's height, four times its footprint) stays in
+            # its tank: the developed flow of a scene the parameters suit.
+            flat = run_single(args, spinup=DEVELOPED_FLOW_STEPS, record_stats=True, scene="dam16m_flat")
+            out["config"]["developed_flow_flat"] = {
+                "state": f"512 x 64 x 512 = 16 777 216 fluid particles (column 0.32 m high) after "
+                         f"{DEVELOPED_FLOW_STEPS} steps of collapse",
+                "particles_total": flat["n"], "grid": flat["gridres"],
+                "ms_per_step": flat["wall"] / steps * 1e3, "value": flat["n_fluid"] * steps / flat["wall"],
+                "unit": "particle-steps/s", "out_of_grid_particles": flat["n_undef"], **flat["stats"],
+                "kernels_ms": {k: (ms / c if c else 0.0) for k, (c, ms) in flat["kernels"].items()}}
+        # ... and the flavour whose whole runs equal the CPU oracle's bit for bit (variant 1), same state as `value`
+        if res.get("variant", 3) != 1:
+            ex = run_single(args, variant=1)
+            out["value_exact"] = {
+                "kernel_variant": VARIANT_NAMES[1], "ms_per_step": ex["wall"] / steps * 1e3,
+                "value": ex["n_fluid"] * steps / ex["wall"], "unit": "particle-steps/s",
+                "kernels_ms": {k: (ms / c if c else 0.0) for k, (c, ms) in ex["kernels"].items()}}
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(res["scene"], args.scene)
     print(json.dumps(out))

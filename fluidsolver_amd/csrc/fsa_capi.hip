@@ -291,7 +291,9 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
     s->slab = p->slab_nz > 0;
     // experiment switches, read here once and never in a launch path
     if (const char *e = getenv("FSA_XCD_RUN_LOG")) s->xcd_run_log = std::min(12, std::max(0, atoi(e)));
+#ifdef FSA_ABLATE
     if (const char *e = getenv("FSA_FAST_DBG")) s->dbg_fast = atoi(e);
+#endif
     if (const char *e = getenv("FSA_WALL_PASS")) s->wall_mode = atoi(e) == 0 ? 1 : 2;
 
     int rc = activate(s);

@@ -795,8 +795,18 @@ extern "C" int fsa_sort_particle_static(const fsa_params *p, int device, void *h
     int ndev = 0;
     FSA_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(FSA_ERR_INVALID, "device %d of %d", device, ndev);
-    FSA_HIP(hipSetDevice(device));
     if (n == 0) return FSA_OK;
+    // the calling thread's current device is put back before returning, whatever happens in between
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    int prev = -1;
+    FSA_HIP(hipGetDevice(&prev));
+    if (prev != device) {
+        FSA_HIP(hipSetDevice(device));
+        guard.prev = prev;
+    }
     int *base = nullptr;
     rc = static_scratch(device, &base);
     if (rc) return rc;

@@ -67,7 +67,7 @@ struct Member {
 struct Group {
     int kind = 0;  // 0 LOCAL, 1 RCCL
     bool overlap = true;
-    int world = 0, halo = 0, record_cap = 0, rb = 0;
+    int world = 0, halo = 0, record_cap = 0, rb = 0, slack = 4096;
     std::vector<int> cuts;
     std::vector<Member> m;
     ncclComm_t comm = nullptr;
@@ -80,9 +80,16 @@ static bool overlap_wanted() {
     return !(e && e[0] == '0');
 }
 
-static int next_size(int count, int cap) {
-    const long long v = (long long)count + count / 8 + 4096;
-    return (int)std::min<long long>(v, cap);
+// Head room of a message over the count it is sized from, in records beyond the 12.5 %.  FSA_SLAB_MSG_SLACK (read when
+// a group is made; may be negative, which makes messages too small on purpose: tests of the cut counts).
+static int slack_wanted() {
+    const char *e = getenv("FSA_SLAB_MSG_SLACK");
+    return e ? atoi(e) : 4096;
+}
+
+static int next_size(int count, int cap, int slack) {
+    const long long v = (long long)count + count / 8 + slack;
+    return (int)std::max<long long>(0, std::min<long long>(v, cap));
 }
 
 #define FSA_NCCL(expr)                                                                                       \
@@ -203,20 +210,23 @@ static int outgoing_sizes(Group &g, Member &mb, long long msg) {
         const int slot = (int)((msg - kLag) % kRing);
         FSA_HIP(counted_event_sync(mb.ev_pack[slot]));  // long done: no wait in steady state
         const int *mi = mb.mirror + slot * kMirrorInts;
-        for (int d = 0; d < 2; d++) mb.size_out[d] = next_size(mi[d], g.record_cap);
+        for (int d = 0; d < 2; d++) mb.size_out[d] = next_size(mi[d], g.record_cap, g.slack);
         g.sent += (long long)mi[0] + mi[1];
     }
     return FSA_OK;
 }
 
-// RCCL: the sizes of the two incoming messages of step `msg`, from the headers received kLag steps before.
+// The sizes of the two incoming messages of step `msg`, from the headers received kLag steps before: what the
+// RCCL transport posts its receives with.  (The local transport copies what the sender sized and uses this only to
+// check that both ends arrive at the same number, which between processes nothing else would notice before the
+// send and the receive disagree.)
 static int incoming_sizes(Group &g, Member &mb, long long msg, int size_in[2]) {
     size_in[0] = size_in[1] = g.record_cap;
     if (msg >= kLag) {
         const int slot = (int)((msg - kLag) % kRing);
         FSA_HIP(counted_event_sync(mb.ev_unpack[slot]));
         const int *mi = mb.mirror + slot * kMirrorInts;
-        for (int d = 0; d < 2; d++) size_in[d] = next_size(mi[4 + d], g.record_cap);
+        for (int d = 0; d < 2; d++) size_in[d] = next_size(mi[4 + d], g.record_cap, g.slack);
     }
     return FSA_OK;
 }
@@ -273,6 +283,20 @@ static int transport(Group &g, long long msg) {
             }
             s->stream = main;  // (before any return)
             FSA_HIP(err);
+        }
+        // the receiving ends derive their sizes as they would under RCCL: they must be the senders' sizes
+        for (Member &mb : g.m) {
+            int size_in[2] = {0, 0};
+            int rc = incoming_sizes(g, mb, msg, size_in);
+            if (rc) return rc;
+            for (int d = 0; d < 2; d++) {
+                if (!mb.recv[d]) continue;
+                const Member &peer = g.m[mb.rank + (d == 0 ? -1 : 1)];
+                if (size_in[d] != peer.size_out[1 - d])
+                    return fail(FSA_ERR_INVALID, "slab group: message %lld from slab %d to slab %d is sized %d records by "
+                                                 "the sender and %d by the receiver", msg, peer.rank, mb.rank,
+                                peer.size_out[1 - d], size_in[d]);
+            }
         }
     } else {
         Member &mb = g.m[0];
@@ -421,6 +445,7 @@ int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts
     if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
     g->kind = 0;
     g->overlap = overlap_wanted();
+    g->slack = slack_wanted();
     g->world = world;
     g->halo = halo;
     g->record_cap = record_cap;
@@ -462,6 +487,7 @@ int fsa_slab_group_create_rccl(fsa_solver *solver, int rank, int world, const ch
     if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
     g->kind = 1;
     g->overlap = overlap_wanted();
+    g->slack = slack_wanted();
     g->world = world;
     g->halo = halo;
     g->record_cap = record_cap;

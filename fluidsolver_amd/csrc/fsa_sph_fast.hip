@@ -108,7 +108,11 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
     __shared__ unsigned wallBits[2][kWallWords];
     __shared__ float queue[EVAL ? Q * BS : 1];
     const int tid = threadIdx.x;
-    const int dbg = run_log >> 8;
+#ifdef FSA_ABLATE
+    const int dbg = run_log >> 8;  // experiment switches of a measurement build (results are then wrong)
+#else
+    constexpr int dbg = 0;
+#endif
     run_log &= 255;
     n = live_count(P, n);
     const int blk = xcd_block(run_log);
@@ -477,7 +481,11 @@ __global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, i
     __shared__ Segments sg;
     __shared__ PairTile<ROWCAP> tile;
     const int tid = threadIdx.x;
-    const int dbg = run_log >> 8;
+#ifdef FSA_ABLATE
+    const int dbg = run_log >> 8;  // experiment switches of a measurement build (results are then wrong)
+#else
+    constexpr int dbg = 0;
+#endif
     run_log &= 255;
     const int quorum = (dbg >> 4) ? (dbg >> 4) : 40;
     // the wall pass has run: its list starts empty at the next density pass (Solver::wall_list_clean)

@@ -563,18 +563,20 @@ def _bench_distributed(args, build_scene):
     use_nccl = (len(set(idents)) == world) if forced is None else forced == "nccl"
     record_group = None
     if use_nccl:
-        # the communicator is created here and now (device_id given); if any rank cannot, all ranks
-        # agree to stage the records through the host instead and the bench line says so
+        # The communicator is created here and now (device_id given).  A rank with a GPU of its own that cannot make
+        # it is an error, not a reason to measure something else: the job ends non-zero on every rank.  (The host-staged
+        # transport is for ranks that share a card, and for FSA_SLAB_BACKEND=gloo.)
         try:
             record_group = dist.new_group(backend="nccl", device_id=device)
             ok = 1
         except Exception as exc:  # noqa: BLE001
-            print(f"rank {rank}: RCCL group creation failed ({exc}); records will be staged over gloo", file=sys.stderr)
+            print(f"rank {rank}: RCCL group creation failed ({exc})", file=sys.stderr)
             ok = 0
         oks = [None] * world
         dist.all_gather_object(oks, ok)
         if not all(oks):
-            record_group, use_nccl = None, False
+            raise SystemExit(f"rank {rank}: ranks {[r for r, o in enumerate(oks) if not o]} could not make the RCCL "
+                             "communicator; set FSA_SLAB_BACKEND=gloo to stage the records through the host instead")
     backend = "nccl" if use_nccl else "gloo"
     # Every rank builds the particles of its own layers only: first the scene's per-layer histogram (the fluid
     # lattice contributes one count per z value, the walls are a thin shell), from it the cuts, then the window.
@@ -626,20 +628,21 @@ def _bench_distributed(args, build_scene):
 
     group = None
     if native:
-        # if any rank cannot make its communicator, all ranks agree on the torch transport and the bench line says so
+        # every rank has its own GPU here; a rank that cannot make the library's group ends the job non-zero on all
+        # ranks (FSA_SLAB_NATIVE=0 selects the torch transport on purpose)
+        err = None
         try:
             group = make_group()
         except Exception as exc:  # noqa: BLE001
-            print(f"rank {rank}: the library's slab group could not be made ({exc}); using the torch transport",
-                  file=sys.stderr)
+            err = str(exc)
+            print(f"rank {rank}: the library's slab group could not be made ({exc})", file=sys.stderr)
         made = [None] * world
         dist.all_gather_object(made, group is not None)
         if not all(made):
             if group is not None:
                 group.close()
-                group = None
-            native = False
-            ss._make_exchange_buffers()
+            raise SystemExit(f"rank {rank}: the library's slab group could not be made on ranks "
+                             f"{[r for r, m in enumerate(made) if not m]}" + (f" ({err})" if err else ""))
     recut_every = getattr(args, "recut_every", 0) or 0
 
     def run(nsteps):

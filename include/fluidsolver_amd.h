@@ -287,6 +287,13 @@ int fsa_step_iisph(fsa_solver *s, int nsteps);
  * the process ends).  Hence the limits: n <= FSA_SORT_STATIC_MAX_PARTICLES and gridres[0] * gridres[1] *
  * layers <= FSA_SORT_STATIC_MAX_CELLS, beyond which the call fails with FSA_ERR_CAPACITY.  All calls on one
  * GPU share that array: calls that overlap on one GPU (two streams, two threads) race.
+ *
+ * The first call on a GPU looks up the array's device address (hipGetSymbolAddress, which may load the
+ * library's code on that GPU): make that first call outside a stream capture; every later call on that GPU is
+ * kernel launches and one hipMemsetAsync only and can be captured.  The calling thread's current device is
+ * left as it was.  The rank inside a cell compares every pair of its particles (the solver's own rank pass
+ * does the same): a cell crowded with k particles costs k^2 comparisons, so positions that pile thousands of
+ * particles into one cell make the call slow (the solvers' scenes hold 8 to 30 per cell).
  */
 #define FSA_SORT_STATIC_MAX_PARTICLES 1048576
 #define FSA_SORT_STATIC_MAX_CELLS 1048576

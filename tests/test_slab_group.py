@@ -104,6 +104,41 @@ def test_group_reports_an_outgrown_message():
         ss.close()
 
 
+@pytest.mark.parametrize("tight", [False, True])
+def test_both_ends_size_the_messages_alike_also_when_counts_are_cut(tight, monkeypatch):
+    """a message is sized from the count of three steps before on both ends (the sender from its own count, the
+    receiver from the header it got); between processes a disagreement would be a send and a receive of different
+    sizes.  The local transport derives the receiver's number too and fails the step if the two differ: run with no
+    head room, and with messages that are too small on purpose (a fifth of a typical count short), so that counts
+    outgrow them and are cut"""
+    sc = SCENES["ddam"]()
+
+    def run(slack):
+        monkeypatch.setenv("FSA_SLAB_MSG_SLACK", str(slack))
+        ranks = make_ranks(sc, 3)
+        g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                                 max(ss.record_cap for ss in ranks))
+        try:
+            g.step(40)             # (a disagreement raises here: "sized ... by the sender and ... by the receiver")
+            return g.sync()
+        finally:
+            g.close()
+            for ss in ranks:
+                ss.close()
+
+    st = run(4096)
+    per_message = st.records_sent / (st.steps * 4)   # three slabs: four messages per step
+    assert per_message > 50
+    if not tight:                  # counts may or may not outgrow a message without head room
+        try:
+            assert run(0).error_bits == 0
+        except capi.FsaError as e:
+            assert "outgrew" in str(e)
+    else:
+        with pytest.raises(capi.FsaError, match="outgrew"):
+            run(-int(per_message * 0.125 + per_message * 0.2))
+
+
 def test_group_refuses_unfit_solvers():
     sc = SCENES["dam"]()
     ranks = make_ranks(sc, 2)

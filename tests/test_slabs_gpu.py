@@ -126,3 +126,39 @@ def test_slab_solver_rejects_static_attributes():
     with pytest.raises(capi.FsaError):
         s.slab_pack((0, 6), (0, 7), (0, 0), (0, 0), 0, 0, 0, 0)
     s.close()
+
+
+def _bench_two_ranks_on_one_gpu(backend, tmp_path):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, FSA_SLAB_BACKEND=backend, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--spinup", "2", "--scene", "dam128k", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            line = json.loads(ln)
+    return r, line
+
+
+def test_bench_ends_non_zero_when_the_rccl_group_cannot_be_made(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it, here with both ranks on the one GPU and RCCL asked for: RCCL
+    refuses two ranks on one device, and the job must end non-zero on that instead of quietly timing the host-staged
+    transport; asked for by name (FSA_SLAB_BACKEND=gloo), that transport runs and the line says which it was"""
+    r, line = _bench_two_ranks_on_one_gpu("nccl", tmp_path)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert line is None
+    assert "RCCL" in r.stderr
+    r, line = _bench_two_ranks_on_one_gpu("gloo", tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["config"]["comm_backend"] == "gloo"
+    assert "torch.distributed transport" in line["config"]["slab_step"]

@@ -55,6 +55,46 @@ def test_static_sort_matches_solver_twice():
         assert np.array_equal(i, i_ref)
 
 
+def test_static_sort_allocates_nothing_and_runs_under_stream_capture():
+    """what the entry point exists for: after the first call on a GPU a call changes no free device memory, and it
+    can be recorded into a graph under a capture that rejects every allocation (global capture mode), whose replay
+    gives the same hash and permutation"""
+    import torch
+    sc = _scene(24, 16, 12, seed=9, outside=11)
+    p, h_ref, i_ref = _solver_sort(sc)
+    n = len(sc["pos"])
+    d_pos = torch.from_numpy(np.ascontiguousarray(sc["pos"], np.float32)).cuda()
+    d_hash = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    d_index = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+
+    def call(stream):
+        capi.sort_particle_static(p, n, d_pos.data_ptr(), d_hash.data_ptr(), d_index.data_ptr(), device=0,
+                                  stream_ptr=stream.cuda_stream)
+
+    call(side)                       # first call on this GPU (it may be the process's first): address look-up
+    side.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    call(side)
+    side.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0
+    assert np.array_equal(d_hash.cpu().numpy(), h_ref) and np.array_equal(d_index.cpu().numpy(), i_ref)
+
+    d_hash.fill_(-7)
+    d_index.fill_(-7)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="global"):
+        call(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert int(d_hash[0]) == -7      # captured, not run
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_hash.cpu().numpy(), h_ref) and np.array_equal(d_index.cpu().numpy(), i_ref)
+    assert torch.cuda.current_device() == 0
+
+
 def test_static_sort_limits_and_empty():
     import torch
     sc = scenes.dam_break(8, 8, 8)
