@@ -979,46 +979,44 @@ int fsa_update_position(fsa_solver *hs) {
     return FSA_OK;
 }
 
+// Both loops queue all their rounds at once; the maximum of error[] and the test against the threshold run on the
+// device after each density-change pass, and the passes of the rounds after the stop return at once.  The host waits
+// only if the caller asks for the iteration count or the last error (one read-back).
 int fsa_correct_density_error(fsa_solver *hs, int maxiter, double ethres, int *iterations, double *last_error) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    int iter = 0, rc = FSA_OK;
-    double error = 0.0;
+    TRY(launch_dfsph_loop_begin(s));
+    int rc = FSA_OK;
     s->dfsph_chain = 1;  // the passes hand their packed records on to each other
-    while (iter < maxiter && !rc) {
+    for (int iter = 0; iter < maxiter && !rc; iter++) {
         rc = fsa_solve_density_stiff(hs);
-        if (!rc) rc = launch_max_error(s, -9999.0, &error);  // solver/sph_solver.cu:176
-        if (rc || error < ethres) break;
-        rc = fsa_apply_pstiff(hs);
-        iter++;
+        if (!rc) rc = launch_dfsph_round_end(s, -9999.0, ethres);  // solver/sph_solver.cu:176-180
+        if (!rc) rc = fsa_apply_pstiff(hs);
     }
     s->dfsph_chain = 0;
+    dfsph_loop_end(s);
     if (rc) return rc;
     TRY(fsa_update_position(hs));
-    if (iterations) *iterations = iter;
-    if (last_error) *last_error = error;
+    if (iterations || last_error) TRY(launch_dfsph_loop_result(s, -9999.0, iterations, last_error));
     return FSA_OK;
 }
 
 int fsa_correct_divergence_error(fsa_solver *hs, int maxiter, double ethres, int *iterations, double *last_error) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    int iter = 0;
-    double error = 0.0;
+    TRY(launch_dfsph_loop_begin(s));
     s->dfsph_chain = 1;  // the passes hand their packed records on to each other
     int rc = fsa_solve_divergence_stiff(hs);  // the extra first launch of solver/sph_solver.cu:226
-    while (iter < maxiter && !rc) {
+    for (int iter = 0; iter < maxiter && !rc; iter++) {
         rc = fsa_solve_divergence_stiff(hs);
-        if (!rc) rc = launch_max_error(s, 0.0, &error);
-        if (rc || error < ethres) break;
-        rc = fsa_apply_pstiff(hs);
-        iter++;
+        if (!rc) rc = launch_dfsph_round_end(s, 0.0, ethres);
+        if (!rc) rc = fsa_apply_pstiff(hs);
     }
     s->dfsph_chain = 0;
+    dfsph_loop_end(s);
     if (rc) return rc;
     TRY(fsa_update_velocities(hs));
-    if (iterations) *iterations = iter;
-    if (last_error) *last_error = error;
+    if (iterations || last_error) TRY(launch_dfsph_loop_result(s, 0.0, iterations, last_error));
     return FSA_OK;
 }
 

@@ -9,6 +9,8 @@
 // Arithmetic follows the reference text operation for operation (explicit casts where its double
 // literals promote a float expression).
 #include "fsa_fast.h"
+#include <cstring>
+
 #include "fsa_pass.h"
 
 namespace fsa {
@@ -681,6 +683,104 @@ int launch_max_error(Solver *s, double start, double *out) {
         FSA_HIP(counted_stream_sync(s->stream));
         *out = v;
     }
+    return FSA_OK;
+}
+
+
+// ---- the two correction loops with the stop test on the device ---------------------------------------------
+// The reference copies error[] to the host after every density-change pass and stops when its maximum is below the
+// threshold (solver/sph_solver.cu:169-186, 226-243).  Here all rounds are queued at once: after each density-change pass
+// two small kernels take the maximum and apply the test on the device, and once it has fired the pass kernels of
+// the remaining rounds return at their first instruction (DevParams::halt).  State behind the block maxima in
+// reduce_tmp: {last maximum} as a double, one spare, then {applyPStiff passes done, stop} as ints.
+constexpr int kLoopState = kReduceBlocks + 8;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void halted_block_max_kernel(int n, const T *__restrict__ in, T start,
+                                                                  T *__restrict__ out, const int *__restrict__ halt) {
+    if (*halt) return;
+    __shared__ T part[kBlock / 64];
+    T m = start;
+    strided_fold(in, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, n, m, [](T &a, T v) { a = v > a ? v : a; });
+    for (int d = 32; d >= 1; d >>= 1) {
+        const T o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) m = part[w] > m ? part[w] : m;
+        out[blockIdx.x] = m;
+    }
+}
+
+// One block: the maximum of the block maxima (folded as block_max_kernel folds them) and the test `error < ethres`.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dfsph_round_end_kernel(int nb, T start, double ethres, const T *__restrict__ part_in,
+                                                                 double *__restrict__ st) {
+    int *ist = reinterpret_cast<int *>(st + 2);
+    if (ist[1]) return;
+    __shared__ T part[kBlock / 64];
+    T m = start;
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+        const T v = part_in[i];
+        m = v > m ? v : m;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const T o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) m = part[w] > m ? part[w] : m;
+        st[0] = (double)m;
+        if ((double)m < ethres)
+            ist[1] = 1;
+        else
+            ist[0] += 1;  // applyPStiff follows
+    }
+}
+
+int launch_dfsph_loop_begin(Solver *s) {
+    double *st = (double *)s->b.reduce_tmp + kLoopState;
+    FSA_HIP(hipMemsetAsync(st, 0, 4 * sizeof(double), s->stream));
+    s->pf.halt = s->pd.halt = reinterpret_cast<const int *>(st + 2) + 1;
+    return FSA_OK;
+}
+
+int launch_dfsph_round_end(Solver *s, double start, double ethres) {
+    if (s->n == 0) return FSA_OK;
+    ScopedTimer t(s, "max_error");
+    const int nb = std::min(kReduceBlocks, blocks_for(s->n));
+    double *st = (double *)s->b.reduce_tmp + kLoopState;
+    if (s->precision == FSA_PRECISION_F32) {
+        hipLaunchKernelGGL(halted_block_max_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, s->n,
+                           (const float *)s->b.error, (float)start, (float *)s->b.reduce_tmp, s->pf.halt);
+        hipLaunchKernelGGL(dfsph_round_end_kernel<float>, dim3(1), dim3(kBlock), 0, s->stream, nb, (float)start, ethres,
+                           (const float *)s->b.reduce_tmp, st);
+    } else {
+        hipLaunchKernelGGL(halted_block_max_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, s->n,
+                           (const double *)s->b.error, start, (double *)s->b.reduce_tmp, s->pf.halt);
+        hipLaunchKernelGGL(dfsph_round_end_kernel<double>, dim3(1), dim3(kBlock), 0, s->stream, nb, start, ethres,
+                           (const double *)s->b.reduce_tmp, st);
+    }
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+// The kernels queued after this run unconditionally again.
+void dfsph_loop_end(Solver *s) { s->pf.halt = s->pd.halt = nullptr; }
+
+// One read-back: how many applyPStiff passes ran and the last maximum.
+int launch_dfsph_loop_result(Solver *s, double start, int *iterations, double *last_error) {
+    double st[3] = {0, 0, 0};
+    FSA_HIP(hipMemcpyAsync(st, (const double *)s->b.reduce_tmp + kLoopState, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
+    int ist[2];
+    std::memcpy(ist, &st[2], sizeof(ist));
+    if (iterations) *iterations = s->n == 0 ? 0 : ist[0];
+    if (last_error) *last_error = s->n == 0 ? start : st[0];
     return FSA_OK;
 }
 

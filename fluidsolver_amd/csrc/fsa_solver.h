@@ -213,6 +213,10 @@ int launch_iisph_new_pressure(Solver *s);
 int launch_iisph_pressure_force(Solver *s);
 int launch_iisph_integrate(Solver *s);
 int launch_mean_error(Solver *s, double *out);  // synchronises
+int launch_dfsph_loop_begin(Solver *s);  // the DFSPH correction loops with their stop test on the device ...
+int launch_dfsph_round_end(Solver *s, double start, double ethres);  // ... maximum of error[] and the test
+void dfsph_loop_end(Solver *s);
+int launch_dfsph_loop_result(Solver *s, double start, int *iterations, double *last_error);  // synchronises once
 int launch_iisph_rounds_begin(Solver *s);  // the pressure rounds with their stop test on the device ...
 int launch_iisph_round_end(Solver *s);     // ... mean of error[] and the test, after each round
 int launch_iisph_rounds_finish(Solver *s, int launched, int *done, double *mean);  // synchronises once

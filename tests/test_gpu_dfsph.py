@@ -259,3 +259,35 @@ def test_v_star_is_reordered_with_the_particles_in_the_wcsph_step_too(orc32):
     assert s.get("v_star").tobytes() == st["v_star"].tobytes()
     s.close()
     st.close()
+
+
+def test_dfsph_steps_are_queued_without_host_waits():
+    """the two correction loops test their stop conditions on the device: whole steps are queued without the host
+    waiting for the stream or the device even once (the library counts its own waits), and the loops still run the
+    same number of iterations and give the same bits as when the caller asks for the counts (one read-back each)"""
+    lib = capi.load()
+    sc = scene("compressed")
+    _, a = gpu_solver(sc)
+    _, b = gpu_solver(sc)
+    for s in (a, b):
+        s.setup_dfsph()
+        s.step_dfsph(1)
+        s.synchronize()
+    before = lib.fsa_debug_host_waits()
+    a.step_dfsph(3)
+    assert lib.fsa_debug_host_waits() == before
+    a.synchronize()
+    iters = []
+    for _ in range(3):
+        b.compute_non_pressure_force()
+        w0 = lib.fsa_debug_host_waits()
+        iters.append(b.correct_density_error(5, 1.0)[0])
+        assert lib.fsa_debug_host_waits() - w0 == 1
+        b.sort_particles()
+        b.compute_density_alpha()
+        iters.append(b.correct_divergence_error(5, 1.0)[0])
+    assert max(iters) > 0
+    for k in ("pos", "vel", "v_star", "pstiff", "error"):
+        assert a.get(k).tobytes() == b.get(k).tobytes(), k
+    a.close()
+    b.close()
