@@ -31,6 +31,8 @@ EXPORTS = (
     "fsa_timing_enable", "fsa_timing_reset", "fsa_timing_read", "fsa_set_variant", "fsa_set_neighbour_lists",
     "fsa_slab_record_bytes", "fsa_slab_pack", "fsa_slab_unpack", "fsa_slab_set_owned", "fsa_slab_export_owned",
     "fsa_set_scene_has_rigid", "fsa_sort_particle_static",
+    "fsa_slab_enable_iisph", "fsa_slab_pack_carry", "fsa_slab_unpack_carry", "fsa_slab_layer_indices",
+    "fsa_slab_gather_field", "fsa_slab_scatter_field", "fsa_slab_owned_sum",
     "fsa_slab_group_create_local", "fsa_slab_group_unique_id", "fsa_slab_group_create_rccl", "fsa_slab_group_step",
     "fsa_slab_group_sync", "fsa_slab_group_rccl_loopback", "fsa_slab_group_destroy",
     "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
@@ -147,6 +149,14 @@ def load() -> C.CDLL:
         "fsa_slab_set_owned": [H, C.POINTER(C.c_int)],
         "fsa_slab_export_owned": [H, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)],
         "fsa_set_scene_has_rigid": [H, C.c_int],
+        "fsa_slab_enable_iisph": [H, C.c_int, C.c_void_p, C.c_void_p],
+        "fsa_slab_pack_carry": [H] + [C.POINTER(C.c_int)] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                                 C.c_void_p, C.c_int, C.POINTER(C.c_int)],
+        "fsa_slab_unpack_carry": [H, C.c_void_p, C.c_void_p, C.c_int],
+        "fsa_slab_layer_indices": [H, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)],
+        "fsa_slab_gather_field": [H, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p],
+        "fsa_slab_scatter_field": [H, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p],
+        "fsa_slab_owned_sum": [H, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)],
         "fsa_slab_group_create_local": [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                         C.POINTER(C.c_void_p)],
         "fsa_slab_group_unique_id": [C.c_char_p],
@@ -439,6 +449,45 @@ class Solver:
 
     def set_scene_has_rigid(self, flag: bool):
         check(self.lib.fsa_set_scene_has_rigid(self._h, 1 if flag else 0))
+
+    # -- the IISPH step on slab solvers (pointers are device addresses) ---------------------
+    def slab_enable_iisph(self, group, normal):
+        """group / normal of the whole scene, indexed by the global unique ids"""
+        g = np.ascontiguousarray(group, np.int32)
+        nrm = np.ascontiguousarray(normal, self.dtype).reshape(-1, 3)
+        assert len(g) == len(nrm)
+        check(self.lib.fsa_slab_enable_iisph(self._h, len(g), _ptr(g), _ptr(nrm)))
+
+    def slab_pack_carry(self, own, keep, left, right, send_left_ptr, extra_left_ptr, cap_left, send_right_ptr,
+                        extra_right_ptr, cap_right):
+        i2 = C.c_int * 2
+        counts = (C.c_int * 4)()
+        check(self.lib.fsa_slab_pack_carry(self._h, i2(*own), i2(*keep), i2(*left), i2(*right),
+                                           C.c_void_p(send_left_ptr), C.c_void_p(extra_left_ptr), int(cap_left),
+                                           C.c_void_p(send_right_ptr), C.c_void_p(extra_right_ptr), int(cap_right),
+                                           counts))
+        return tuple(counts)
+
+    def slab_unpack_carry(self, records_ptr, extras_ptr, count):
+        check(self.lib.fsa_slab_unpack_carry(self._h, C.c_void_p(records_ptr), C.c_void_p(extras_ptr), int(count)))
+
+    def slab_layer_indices(self, lo, hi, idx_ptr, cap) -> int:
+        n = C.c_int()
+        check(self.lib.fsa_slab_layer_indices(self._h, int(lo), int(hi), C.c_void_p(idx_ptr), int(cap), C.byref(n)))
+        return n.value
+
+    def slab_gather_field(self, name, idx_ptr, count, out_ptr):
+        check(self.lib.fsa_slab_gather_field(self._h, name.encode(), C.c_void_p(idx_ptr), int(count),
+                                             C.c_void_p(out_ptr)))
+
+    def slab_scatter_field(self, name, idx_ptr, count, in_ptr):
+        check(self.lib.fsa_slab_scatter_field(self._h, name.encode(), C.c_void_p(idx_ptr), int(count),
+                                              C.c_void_p(in_ptr)))
+
+    def slab_owned_sum(self, name, own) -> float:
+        v = C.c_double()
+        check(self.lib.fsa_slab_owned_sum(self._h, name.encode(), (C.c_int * 2)(*own), C.byref(v)))
+        return v.value
 
     # -- measurement ------------------------------------------------------------------
     def timing_enable(self, on=True): check(self.lib.fsa_timing_enable(self._h, 1 if on else 0))

@@ -774,7 +774,7 @@ int fsa_get_buffer(fsa_solver *hs, const char *name, void *dst, size_t bytes) {
     if (k == "pstiff") { TRY(want(N * R)); return copy_out(s, s->b.pstiff, dst, bytes); }
     if (k == "error") { TRY(want(N * R)); return copy_out(s, s->b.error, dst, bytes); }
     if (k == "dii" || k == "dijpjl" || k == "pressureForce" || k == "aii" || k == "density_star") {
-        if (s->slab) return fail(FSA_ERR_INVALID, "a slab solver has no IISPH buffers");
+        if (s->slab && !s->slab_carry) return fail(FSA_ERR_INVALID, "a slab solver has no IISPH buffers");
         const bool vec = k == "dii" || k == "dijpjl" || k == "pressureForce";
         TRY(want(N * (vec ? 3 : 1) * R));
         const void *p = k == "dii" ? s->b.dii : k == "dijpjl" ? s->b.dijpjl : k == "pressureForce" ? s->b.pressureForce
@@ -863,7 +863,7 @@ int fsa_set_buffer(fsa_solver *hs, const char *name, const void *src, size_t byt
     if (k == "DF_factor") return plain(s->b.DF_factor, N * R);
     if (k == "pstiff") return plain(s->b.pstiff, N * R);
     if (k == "error") return plain(s->b.error, N * R);
-    if (!s->slab) {
+    if (!s->slab || s->slab_carry) {
         if (k == "dii") return plain(s->b.dii, N * 3 * R);
         if (k == "dijpjl") return plain(s->b.dijpjl, N * 3 * R);
         if (k == "pressureForce") return plain(s->b.pressureForce, N * 3 * R);
@@ -1041,7 +1041,8 @@ int fsa_step_dfsph(fsa_solver *hs, int nsteps) {
 // Marks the solver as running the IISPH step: from then on every sort also carries pressure[] and keeps
 // the per-position copy of group[] current.  The first call brings that copy up to date.
 static int enter_iisph(Solver *s, const char *who) {
-    if (s->slab) return fail(FSA_ERR_INVALID, "%s is not available in a slab solver", who);
+    if (s->slab && !s->slab_carry)
+        return fail(FSA_ERR_INVALID, "%s: a slab solver runs the IISPH step only after fsa_slab_enable_iisph", who);
     if (s->iisph) return FSA_OK;
     s->iisph = true;
     if (s->n == 0) return FSA_OK;
@@ -1228,6 +1229,145 @@ int fsa_slab_unpack(fsa_solver *hs, const void *d_records, int count) {
     s->count_valid = false;
     s->owned_from_sort = false;
     return FSA_OK;
+}
+
+// ---- the IISPH step on slab solvers ------------------------------------------------------------
+int fsa_slab_enable_iisph(fsa_solver *hs, int n_global, const int *group, const void *normal3) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_enable_iisph needs a solver created with slab_nz > 0");
+    if (n_global <= 0 || !group || !normal3) return fail(FSA_ERR_INVALID, "bad argument");
+    FSA_HIP(counted_stream_sync(s->stream));
+    const size_t N = (size_t)s->capacity, R = s->real_size(), G = (size_t)n_global;
+    Buffers &b = s->b;
+    if (!s->slab_carry) {
+        TRY(dalloc(b.pressure_alt, N * R, true));
+        TRY(dalloc(b.dii, N * 3 * R, true));
+        TRY(dalloc(b.dijpjl, N * 3 * R, true));
+        TRY(dalloc(b.pressureForce, N * 3 * R, true));
+        TRY(dalloc(b.aii, N * R, true));
+        TRY(dalloc(b.density_star, N * R, true));
+        TRY(dalloc(b.groupSorted, N * sizeof(int), true));
+    }
+    if (s->table_n != n_global) {
+        if (b.group) (void)hipFree(b.group);
+        if (b.normal) (void)hipFree(b.normal);
+        b.group = nullptr;
+        b.normal = nullptr;
+        s->table_n = 0;
+        TRY(dalloc(b.group, G * sizeof(int), false));
+        TRY(dalloc(b.normal, G * 3 * R, false));
+        s->table_n = n_global;
+    }
+    FSA_HIP(hipMemcpy(b.group, group, G * sizeof(int), hipMemcpyHostToDevice));
+    FSA_HIP(hipMemcpy(b.normal, normal3, G * 3 * R, hipMemcpyHostToDevice));
+    s->slab_carry = true;
+    s->iisph = false;  // the per-position copy of group[] is rebuilt by the next IISPH call
+    return FSA_OK;
+}
+
+int fsa_slab_pack_carry(fsa_solver *hs, const int own[2], const int keep[2], const int left[2], const int right[2],
+                        void *d_send_left, void *d_extra_left, int cap_left, void *d_send_right, void *d_extra_right,
+                        int cap_right, int counts[4]) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab || !s->slab_carry) return fail(FSA_ERR_INVALID, "fsa_slab_pack_carry needs fsa_slab_enable_iisph first");
+    if (!own || !keep || !left || !right || !counts) return fail(FSA_ERR_INVALID, "NULL argument");
+    if (cap_left < 0 || cap_right < 0 || (cap_left > 0 && (!d_send_left || !d_extra_left)) ||
+        (cap_right > 0 && (!d_send_right || !d_extra_right)))
+        return fail(FSA_ERR_INVALID, "send buffer missing");
+    if (keep[0] < s->pf.z0 || keep[1] > s->pf.z0 + s->pf.nz)
+        return fail(FSA_ERR_INVALID, "keep range [%d, %d) exceeds the layers [%d, %d) this solver holds", keep[0],
+                    keep[1], s->pf.z0, s->pf.z0 + s->pf.nz);
+    TRY(launch_slab_pack(s, own, keep, left, right, d_send_left, cap_left, d_send_right, cap_right, counts,
+                         d_extra_left, d_extra_right));
+    if (counts[0] > s->capacity)
+        return fail(FSA_ERR_CAPACITY, "%d particles stay, capacity %d", counts[0], s->capacity);
+    if (counts[1] > cap_left || counts[2] > cap_right)
+        return fail(FSA_ERR_CAPACITY, "send buffers too small: %d / %d records for %d / %d slots", counts[1],
+                    counts[2], cap_left, cap_right);
+    s->n = counts[0];
+    s->cur = 1 - s->cur;
+    invalidate_order(s);
+    s->count_valid = false;
+    s->owned_from_sort = false;
+    return FSA_OK;
+}
+
+int fsa_slab_unpack_carry(fsa_solver *hs, const void *d_records, const void *d_extras, int count) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab || !s->slab_carry) return fail(FSA_ERR_INVALID, "fsa_slab_unpack_carry needs fsa_slab_enable_iisph first");
+    if (count < 0 || (count > 0 && (!d_records || !d_extras))) return fail(FSA_ERR_INVALID, "bad record buffer");
+    if ((long long)s->n + count > s->capacity)
+        return fail(FSA_ERR_CAPACITY, "%d + %d particles exceed capacity %d", s->n, count, s->capacity);
+    TRY(launch_slab_unpack(s, d_records, count, d_extras));
+    s->n += count;
+    invalidate_order(s);
+    s->count_valid = false;
+    s->owned_from_sort = false;
+    return FSA_OK;
+}
+
+int fsa_slab_layer_indices(fsa_solver *hs, int layer_lo, int layer_hi, int *d_idx, int cap, int *count) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_layer_indices needs a solver created with slab_nz > 0");
+    if (!count || cap < 0 || (cap > 0 && !d_idx)) return fail(FSA_ERR_INVALID, "bad argument");
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "fsa_slab_layer_indices needs a sorted state");
+    if (layer_lo < s->pf.z0 || layer_hi > s->pf.z0 + s->pf.nz || layer_lo > layer_hi)
+        return fail(FSA_ERR_INVALID, "layers [%d, %d) outside the layers held [%d, %d)", layer_lo, layer_hi, s->pf.z0,
+                    s->pf.z0 + s->pf.nz);
+    return launch_slab_layer_indices(s, layer_lo, layer_hi, d_idx, cap, count);
+}
+
+// the per-particle fields that the neighbour passes of the IISPH step read of a neighbour: device array and reals per particle
+static int slab_field(Solver *s, const char *name, void **ptr, int *reals) {
+    if (!name) return fail(FSA_ERR_INVALID, "NULL argument");
+    const std::string k(name);
+    *ptr = nullptr;
+    *reals = 1;
+    if (k == "density") *ptr = s->b.density;
+    else if (k == "pressure") *ptr = s->b.pressure;
+    else if (k == "restDensity") *ptr = s->b.restDensity[s->cur];
+    else if (k == "error") *ptr = s->b.error;
+    else if (k == "v_star") { *ptr = s->b.v_star; *reals = 3; }
+    else if (k == "dii") { *ptr = s->b.dii; *reals = 3; }
+    else if (k == "dijpjl") { *ptr = s->b.dijpjl; *reals = 3; }
+    if (!*ptr) return fail(FSA_ERR_UNKNOWN_NAME, "field '%s' cannot be moved (or is not allocated in this solver)", name);
+    return FSA_OK;
+}
+
+static int slab_move_field(fsa_solver *hs, bool scatter, const char *name, const int *d_idx, int count, void *d_buf) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (count < 0 || (count > 0 && (!d_idx || !d_buf))) return fail(FSA_ERR_INVALID, "bad argument");
+    void *field = nullptr;
+    int reals = 1;
+    TRY(slab_field(s, name, &field, &reals));
+    if (scatter) s->pd_valid = false;
+    return launch_field_move(s, scatter, field, reals * (int)(s->real_size() / 4), d_idx, count, d_buf);
+}
+
+int fsa_slab_gather_field(fsa_solver *hs, const char *name, const int *d_idx, int count, void *d_out) {
+    return slab_move_field(hs, false, name, d_idx, count, d_out);
+}
+
+int fsa_slab_scatter_field(fsa_solver *hs, const char *name, const int *d_idx, int count, const void *d_in) {
+    return slab_move_field(hs, true, name, d_idx, count, const_cast<void *>(d_in));
+}
+
+int fsa_slab_owned_sum(fsa_solver *hs, const char *name, const int own[2], double *sum) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_owned_sum needs a solver created with slab_nz > 0");
+    if (!own || !sum) return fail(FSA_ERR_INVALID, "NULL argument");
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "fsa_slab_owned_sum needs a sorted state");
+    void *field = nullptr;
+    int reals = 1;
+    TRY(slab_field(s, name, &field, &reals));
+    if (reals != 1) return fail(FSA_ERR_INVALID, "'%s' is not a scalar field", name);
+    return launch_owned_sum(s, own[0], own[1], field, sum);
 }
 
 int fsa_slab_set_owned(fsa_solver *hs, const int own[2]) {

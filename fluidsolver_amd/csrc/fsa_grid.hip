@@ -633,7 +633,10 @@ int launch_reorder(Solver *s) {
                            s->b.cellStart, s->b.sortedHash, s->b.blockRows, s->b.bigBlocks);
         FSA_HIP(hipGetLastError());
     }
-    if (s->slab) return launch_slab_keys(s);
+    if (s->slab) {
+        int rc = launch_slab_keys(s);
+        if (rc) return rc;
+    }
     if (s->iisph) return launch_iisph_carry(s, out);
     return FSA_OK;
 }

@@ -20,6 +20,7 @@
 // classifies, writes the records and computes the next step's hash (dropped slots are marked, not compacted away),
 // a second appends the received records with their hash, and the sort that follows gathers what is left.
 #include <algorithm>
+#include <vector>
 
 #include "fsa_advect.h"
 #include "fsa_hash.h"
@@ -83,6 +84,14 @@ __device__ __forceinline__ unsigned route_outside(const SlabRanges &R, int layer
 
 constexpr int kPackItems = 4;  // particles per thread: one atomic per stream for 1024 particles
 
+// One more scalar per particle that travels with it (the pressure of the IISPH step, whose relaxation starts from
+// the last step's values): kept particles take it to the other copy, records to a buffer beside theirs, slot for
+// slot.  All null when nothing is carried.
+template <typename T> struct SlabExtra {
+    const T *in;
+    T *out, *left, *right;
+};
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
     DevParams<T> P, int n, int all_owned, SlabRanges R, const int *__restrict__ sortedHash,
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
     const int *__restrict__ uniqueIdIn, const long long *__restrict__ keyIn, Vec4<T> *__restrict__ posTypeOut,
     Vec4<T> *__restrict__ velMassOut, T *__restrict__ restDensityOut, int *__restrict__ uniqueIdOut,
     long long *__restrict__ keyOut, int capKeep, SlabRecord<T> *__restrict__ sendLeft, int capLeft,
-    SlabRecord<T> *__restrict__ sendRight, int capRight, int *__restrict__ counters) {
+    SlabRecord<T> *__restrict__ sendRight, int capRight, int *__restrict__ counters, SlabExtra<T> X) {
     constexpr int kWaves = kBlock / 64;
     // per stream (keep, left, right): particles flagged by wave w in item round k, then their prefix
     __shared__ int part[3][kPackItems * kWaves];
@@ -165,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
         const T rd = restDensityIn[i];
         const int uid = uniqueIdIn[i];
         const long long key = keyIn[i];
+        const T extra = X.in ? X.in[i] : (T)0;
         const int e = k * kWaves + wave;
         if (flags[k] & 1u) {
             const int slot = base[0] + part[0][e] + before[k][0];
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
                 restDensityOut[slot] = rd;
                 uniqueIdOut[slot] = uid;
                 keyOut[slot] = key;
+                if (X.in) X.out[slot] = extra;
             }
         }
         if (flags[k] & 6u) {
@@ -185,11 +196,17 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
             rec.uniqueId = uid;
             if (flags[k] & 2u) {
                 const int slot = base[1] + part[1][e] + before[k][1];
-                if (slot < capLeft) sendLeft[slot] = rec;
+                if (slot < capLeft) {
+                    sendLeft[slot] = rec;
+                    if (X.in) X.left[slot] = extra;
+                }
             }
             if (flags[k] & 4u) {
                 const int slot = base[2] + part[2][e] + before[k][2];
-                if (slot < capRight) sendRight[slot] = rec;
+                if (slot < capRight) {
+                    sendRight[slot] = rec;
+                    if (X.in) X.right[slot] = extra;
+                }
             }
         }
     }
@@ -244,10 +261,12 @@ __global__ __launch_bounds__(kBlock) void slab_unpack_kernel(int count, int at, 
                                                              Vec4<T> *__restrict__ posType,
                                                              Vec4<T> *__restrict__ velMass,
                                                              T *__restrict__ restDensity, int *__restrict__ uniqueId,
-                                                             long long *__restrict__ key) {
+                                                             long long *__restrict__ key,
+                                                             const T *__restrict__ extras, T *__restrict__ extra) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= count) return;
     const SlabRecord<T> r = recs[k];
+    if (extras) extra[at + k] = extras[k];
     posType[at + k] = r.posType;
     velMass[at + k] = r.velMass;
     restDensity[at + k] = r.restDensity;
@@ -618,28 +637,34 @@ int launch_slab_keys(Solver *s) {
 
 template <typename T>
 static int pack_t(Solver *s, const DevParams<T> &P, const SlabRanges &R, void *sendLeft, int capLeft, void *sendRight,
-                  int capRight) {
+                  int capRight, void *extraLeft, void *extraRight) {
     const int in = s->cur, out = 1 - s->cur;
+    SlabExtra<T> X{nullptr, nullptr, nullptr, nullptr};
+    if (s->slab_carry) X = SlabExtra<T>{(const T *)s->b.pressure, (T *)s->b.pressure_alt, (T *)extraLeft, (T *)extraRight};
     hipLaunchKernelGGL(slab_pack_kernel<T>, dim3((s->grid_n() + kBlock * kPackItems - 1) / (kBlock * kPackItems)), dim3(kBlock), 0, s->stream, P, s->grid_n(),
                        s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (const Vec4<T> *)s->b.posType[in],
                        (const Vec4<T> *)s->b.velMass[in], (const T *)s->b.restDensity[in], s->b.uniqueId[in],
                        s->b.orderKey[in], (Vec4<T> *)s->b.posType[out], (Vec4<T> *)s->b.velMass[out],
                        (T *)s->b.restDensity[out], s->b.uniqueId[out], s->b.orderKey[out], s->capacity,
-                       (SlabRecord<T> *)sendLeft, capLeft, (SlabRecord<T> *)sendRight, capRight, s->b.slabCounters);
+                       (SlabRecord<T> *)sendLeft, capLeft, (SlabRecord<T> *)sendRight, capRight, s->b.slabCounters, X);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
 
+// extraLeft / extraRight: with Solver::slab_carry, where the carried scalar of each record goes (capLeft / capRight
+// reals), slot for slot beside the records
 int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
-                     void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]) {
+                     void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4], void *extraLeft,
+                     void *extraRight) {
     FSA_HIP(hipMemsetAsync(s->b.slabCounters, 0, 4 * sizeof(int), s->stream));
     if (s->n > 0) {
         ScopedTimer t(s, "slab_pack");
         const SlabRanges R = slab_ranges(own, keep, left, right);
         int rc = s->precision == FSA_PRECISION_F32
-                     ? pack_t<float>(s, s->pf, R, sendLeft, capLeft, sendRight, capRight)
-                     : pack_t<double>(s, s->pd, R, sendLeft, capLeft, sendRight, capRight);
+                     ? pack_t<float>(s, s->pf, R, sendLeft, capLeft, sendRight, capRight, extraLeft, extraRight)
+                     : pack_t<double>(s, s->pd, R, sendLeft, capLeft, sendRight, capRight, extraLeft, extraRight);
         if (rc) return rc;
+        if (s->slab_carry) std::swap(s->b.pressure, s->b.pressure_alt);  // the kept particles' values went there
     }
     FSA_HIP(hipMemcpyAsync(counts, s->b.slabCounters, 4 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     FSA_HIP(counted_stream_sync(s->stream));
@@ -669,19 +694,20 @@ int launch_slab_export(Solver *s, const int own[2], void *recs, int cap, int *co
     return FSA_OK;
 }
 
-int launch_slab_unpack(Solver *s, const void *recs, int count) {
+int launch_slab_unpack(Solver *s, const void *recs, int count, const void *extras) {
     if (count == 0) return FSA_OK;
     ScopedTimer t(s, "slab_unpack");
     const int c = s->cur;
     if (s->precision == FSA_PRECISION_F32)
         hipLaunchKernelGGL(slab_unpack_kernel<float>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, count, s->n,
                            (const SlabRecord<float> *)recs, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
-                           (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c]);
+                           (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c], (const float *)extras,
+                           (float *)s->b.pressure);
     else
         hipLaunchKernelGGL(slab_unpack_kernel<double>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, count,
                            s->n, (const SlabRecord<double> *)recs, (double4 *)s->b.posType[c],
                            (double4 *)s->b.velMass[c], (double *)s->b.restDensity[c], s->b.uniqueId[c],
-                           s->b.orderKey[c]);
+                           s->b.orderKey[c], (const double *)extras, (double *)s->b.pressure);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
@@ -757,6 +783,132 @@ int launch_slab_unpack_hash(Solver *s, const void *recvLeft, int boundLeft, cons
                        (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c], s->b.hash, s->b.slot,
                        s->b.cellCount, s->b.undefBlockCount, mirror);
     FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+
+// ---- field refresh between the neighbour passes of a step that runs many of them (IISPH on slabs) ------------
+// The sorted order of a slab solver is (y, layer, x, order key).  The in-grid particles of the global layers
+// [lo, hi) are therefore, for every y, one contiguous run of the sorted arrays, and two solvers that both hold
+// those layers hold the same particles in the same order.  A solver that owns the layers gathers a field of
+// theirs into a buffer; the neighbour that holds them as halo copies scatters the buffer onto its own: both walk
+// the runs in ascending sorted position.
+
+// offsets[y] = particles of the layers in rows before y; offsets[gy] = their number (one thread: gy is a few hundred)
+__global__ void layer_runs_kernel(int gx, int gy, int nz, int zl0, int zl1, const int *__restrict__ cellStart,
+                                  int *__restrict__ offsets) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int run = 0;
+    for (int y = 0; y < gy; y++) {
+        offsets[y] = run;
+        run += cellStart[((size_t)y * nz + zl1) * gx] - cellStart[((size_t)y * nz + zl0) * gx];
+    }
+    offsets[gy] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void layer_indices_kernel(int gx, int gy, int nz, int zl0, int count,
+                                                               const int *__restrict__ cellStart,
+                                                               const int *__restrict__ offsets,
+                                                               int *__restrict__ idx) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= count) return;
+    int lo = 0, hi = gy - 1;  // the last y whose offset is <= e
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (offsets[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    idx[e] = cellStart[((size_t)lo * nz + zl0) * gx] + (e - offsets[lo]);
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void field_move_kernel(int count, int words, const int *__restrict__ idx,
+                                                            unsigned *__restrict__ field, unsigned *__restrict__ buf) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)count * words) return;
+    const int e = (int)(t / words), w = (int)(t % words);
+    if (SCATTER) field[(size_t)idx[e] * words + w] = buf[t];
+    else buf[t] = field[(size_t)idx[e] * words + w];
+}
+
+// Sum of a[] over the particles this solver owns (cell layer in [lo, hi), or outside the grid), in double, block
+// partial sums folded in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void owned_sum_kernel(DevParams<T> P, int n, int lo, int hi,
+                                                           const int *__restrict__ sortedHash, const T *__restrict__ a,
+                                                           double *__restrict__ part_out) {
+    __shared__ double part[kBlock / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const unsigned h = (unsigned)sortedHash[i];
+        bool owned = h == (unsigned)FSA_GRID_UNDEF;
+        if (!owned) {
+            const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
+            owned = gz >= lo && gz < hi;
+        }
+        if (owned) acc += (double)a[i];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) acc += part[w];
+        part_out[blockIdx.x] = acc;
+    }
+}
+
+int launch_slab_layer_indices(Solver *s, int lo, int hi, int *d_idx, int cap, int *count) {
+    const int gx = s->pf.gres[0], gy = s->pf.gres[1], nz = s->pf.nz, z0 = s->pf.z0;
+    *count = 0;
+    if (lo >= hi) return FSA_OK;
+    // the prefix table lives in the scratch of the block maxima (gy + 1 ints of its 2048 doubles)
+    if (gy + 1 > 4096) return fail(FSA_ERR_INVALID, "gridres[1] = %d: more rows than the run table takes", gy);
+    int *offsets = (int *)s->b.reduce_tmp;
+    hipLaunchKernelGGL(layer_runs_kernel, dim3(1), dim3(64), 0, s->stream, gx, gy, nz, lo - z0, hi - z0, s->b.cellStart, offsets);
+    FSA_HIP(hipGetLastError());
+    int total = 0;
+    FSA_HIP(hipMemcpyAsync(&total, offsets + gy, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
+    *count = total;
+    if (total > cap) return fail(FSA_ERR_CAPACITY, "%d particles in layers [%d, %d) for %d index slots", total, lo, hi, cap);
+    if (total == 0) return FSA_OK;
+    hipLaunchKernelGGL(layer_indices_kernel, dim3(blocks_for(total)), dim3(kBlock), 0, s->stream, gx, gy, nz, lo - z0, total,
+                       s->b.cellStart, offsets, d_idx);
+    FSA_HIP(hipGetLastError());
+    // (the table's scratch is free again once the kernel has run; the passes that use it come later on this stream)
+    return FSA_OK;
+}
+
+int launch_field_move(Solver *s, bool scatter, void *field, int words, const int *d_idx, int count, void *d_buf) {
+    if (count == 0) return FSA_OK;
+    const long long total = (long long)count * words;
+    if (scatter)
+        hipLaunchKernelGGL(field_move_kernel<true>, dim3(blocks_for(total)), dim3(kBlock), 0, s->stream, count, words, d_idx,
+                           (unsigned *)field, (unsigned *)d_buf);
+    else
+        hipLaunchKernelGGL(field_move_kernel<false>, dim3(blocks_for(total)), dim3(kBlock), 0, s->stream, count, words, d_idx,
+                           (unsigned *)field, (unsigned *)d_buf);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+int launch_owned_sum(Solver *s, int lo, int hi, const void *a, double *out) {
+    *out = 0.0;
+    if (s->n == 0) return FSA_OK;
+    const int nb = std::min(1024, blocks_for(s->n));
+    double *tmp = (double *)s->b.reduce_tmp;
+    if (s->precision == FSA_PRECISION_F32)
+        hipLaunchKernelGGL(owned_sum_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, s->pf, s->n, lo, hi, s->b.sortedHash,
+                           (const float *)a, tmp);
+    else
+        hipLaunchKernelGGL(owned_sum_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, s->pd, s->n, lo, hi,
+                           s->b.sortedHash, (const double *)a, tmp);
+    FSA_HIP(hipGetLastError());
+    std::vector<double> h(nb);
+    FSA_HIP(hipMemcpyAsync(h.data(), tmp, nb * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    FSA_HIP(counted_stream_sync(s->stream));
+    double sum = 0.0;
+    for (int b = 0; b < nb; b++) sum += h[b];
+    *out = sum;
     return FSA_OK;
 }
 

@@ -123,6 +123,8 @@ struct Solver {
     bool has_rigid = false;     // some particle is TYPE_RIGID: the density pass needs the rigid term
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
+    bool slab_carry = false;    // slab solver set up for the IISPH step: pack / unpack carry pressure[] (fsa_slab_enable_iisph)
+    int table_n = 0;            // ... and its group / normal tables cover this many (global) unique ids
     int iisph_chain = 0;        // inside fsa_iisph_solve_pressure: 1 first round, 2 later rounds (fsa_iisph.hip)
     bool fluid_mass_uniform = false;  // fp32: every TYPE_FLUID particle has the same mass (checked where the host hands the masses over)
     int dfsph_chain = 0;        // inside the two DFSPH correction loops: 1 before the first pass, 2 after (fsa_dfsph.hip)
@@ -232,8 +234,12 @@ int launch_slab_init_keys(Solver *s);
 int launch_rank_key(Solver *s);
 int launch_slab_keys(Solver *s);
 int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
-                     void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4]);
-int launch_slab_unpack(Solver *s, const void *recs, int count);
+                     void *sendLeft, int capLeft, void *sendRight, int capRight, int counts[4],
+                     void *extraLeft = nullptr, void *extraRight = nullptr);
+int launch_slab_unpack(Solver *s, const void *recs, int count, const void *extras = nullptr);
+int launch_slab_layer_indices(Solver *s, int lo, int hi, int *d_idx, int cap, int *count);  // synchronises
+int launch_field_move(Solver *s, bool scatter, void *field, int words, const int *d_idx, int count, void *d_buf);
+int launch_owned_sum(Solver *s, int lo, int hi, const void *a, double *out);  // synchronises
 int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const int left[2], const int right[2],
                           void *sendLeft, int sizeLeft, void *sendRight, int sizeRight);
 int launch_slab_pack_tail(Solver *s, void *stream, void *sendLeft, int sizeLeft, void *sendRight, int sizeRight,

@@ -333,6 +333,87 @@ class HipSlabBackend:
     def close(self):
         self.solver.close()
 
+    # -- the IISPH step (IisphSlabs below drives these) ------------------------------------------------
+    real_bytes = 4
+
+    def enable_iisph(self, group, normal):
+        self.solver.slab_enable_iisph(group, normal)
+
+    def pack_carry(self, own, keep, left, right, cap):
+        """-> kept, lost, {-1: (record bytes, pressures, count), +1: ...} for the sides that have a neighbour"""
+        t = self.torch
+        rb = self.record_bytes
+        sides = {-1: left[1] > left[0], 1: right[1] > right[0]}
+        if not hasattr(self, "_send") or self._send_cap != cap:
+            self._send_cap = cap
+            self._send = {sd: (t.empty(max(cap, 1) * rb, dtype=t.uint8, device=self.device),
+                               t.empty(max(cap, 1), dtype=t.float32, device=self.device)) for sd in (-1, 1)}
+        (bl, xl), (br, xr) = self._send[-1], self._send[1]
+        kept, nl, nr, lost = self.solver.slab_pack_carry(own, keep, left, right, bl.data_ptr(), xl.data_ptr(),
+                                                         cap if sides[-1] else 0, br.data_ptr(), xr.data_ptr(),
+                                                         cap if sides[1] else 0)
+        out = {}
+        if sides[-1]:
+            out[-1] = (bl[:nl * rb], xl[:nl].view(t.uint8), nl)
+        if sides[1]:
+            out[1] = (br[:nr * rb], xr[:nr].view(t.uint8), nr)
+        return kept, lost, out
+
+    def unpack_carry(self, records, extras, count):
+        if count:
+            records, extras = records.to(self.device).contiguous(), extras.to(self.device).contiguous()
+            self._hold = (records, extras)  # until the kernel has read them (same stream: the next call is ordered)
+            self.solver.slab_unpack_carry(records.data_ptr(), extras.data_ptr(), count)
+
+    def layer_list(self, lo, hi):
+        """sorted positions of the in-grid particles of the global layers [lo, hi)"""
+        t = self.torch
+        cap = max(self.n, 1)
+        idx = t.empty(cap, dtype=t.int32, device=self.device)
+        cnt = self.solver.slab_layer_indices(lo, hi, idx.data_ptr(), cap) if hi > lo else 0
+        return idx[:cnt]
+
+    def gather(self, fields, idx):
+        """the named fields of the listed particles, one after the other, as bytes"""
+        t = self.torch
+        cnt = idx.numel()
+        parts = []
+        for name in fields:
+            buf = t.empty(cnt * IISPH_FIELD_WIDTH[name], dtype=t.float32, device=self.device)
+            self.solver.slab_gather_field(name, idx.data_ptr(), cnt, buf.data_ptr())
+            parts.append(buf.view(t.uint8))
+        return t.cat(parts) if parts else t.empty(0, dtype=t.uint8, device=self.device)
+
+    def scatter(self, fields, idx, data):
+        t = self.torch
+        cnt = idx.numel()
+        data = data.to(self.device).contiguous()
+        self._hold2 = data
+        at = 0
+        for name in fields:
+            nb = cnt * IISPH_FIELD_WIDTH[name] * 4
+            self.solver.slab_scatter_field(name, idx.data_ptr(), cnt, data.data_ptr() + at)
+            at += nb
+        assert at == data.numel(), "field refresh: the two slabs disagree on how many particles the layers hold"
+
+    def field_bytes(self, fields, count):
+        return count * sum(IISPH_FIELD_WIDTH[f] for f in fields) * 4
+
+    def owned_error_sum(self, own):
+        return self.solver.slab_owned_sum("error", own)
+
+    def sort(self): self.solver.sort_particles()
+    def setup_iisph(self): self.solver.setup_iisph()
+    def iisph_factor(self): self.solver.iisph_factor()
+    def iisph_npf(self): self.solver.non_pressure_force_multiphase()
+    def iisph_predict_density(self): self.solver.iisph_predict_density()
+    def iisph_calc_dijpjl(self): self.solver.iisph_calc_dijpjl()
+    def iisph_calc_new_pressure(self): self.solver.iisph_calc_new_pressure()
+    def iisph_update(self): self.solver.iisph_update()
+
+
+IISPH_FIELD_WIDTH = {"density": 1, "pressure": 1, "restDensity": 1, "v_star": 3, "dii": 3, "dijpjl": 3}
+
 
 # ------------------------------------------------------------------------------------------------
 # the distributed solver
@@ -504,6 +585,179 @@ class SlabSolver:
 
     def close(self):
         self.backend.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the IISPH step on slabs
+# ------------------------------------------------------------------------------------------------
+class LocalComm:
+    """Moves buffers between slabs that all live in this process."""
+
+    def swap_counts(self, outgoing):
+        return {(dst, src): n for (src, dst), n in outgoing.items()}
+
+    def swap_bytes(self, outgoing, incoming_sizes):
+        got = {(dst, src): t for (src, dst), t in outgoing.items()}
+        for k, nb in incoming_sizes.items():
+            assert k in got and got[k].numel() == nb, f"message {k[1]} -> {k[0]}: {got[k].numel()} bytes sent, {nb} expected"
+        return got
+
+    def sum(self, values):
+        return float(sum(values))
+
+
+class DistComm:
+    """One slab per process: buffers travel between z-neighbours over torch.distributed point-to-point calls
+    (RCCL for device tensors when the group's backend is "nccl", host staging over gloo otherwise)."""
+
+    def __init__(self, transport):
+        self.t = transport
+
+    def swap_counts(self, outgoing):
+        torch = self.t.torch
+        dev = self.t.comm_device
+        out = {k: torch.tensor([n], dtype=torch.int64, device=dev) for k, n in outgoing.items()}
+        inc = {(src, dst): torch.zeros(1, dtype=torch.int64, device=dev) for (src, dst) in outgoing}
+        self.t._batch([(dst, t) for (src, dst), t in out.items()], [(dst, t) for (src, dst), t in inc.items()])
+        return {(src, dst): int(t.item()) for (src, dst), t in inc.items()}  # keyed (receiver, sender)
+
+    def swap_bytes(self, outgoing, incoming_sizes):
+        torch = self.t.torch
+        dev = self.t.comm_device
+        sends = [(dst, (t.cpu() if self.t.staged else t).contiguous()) for (src, dst), t in outgoing.items() if t.numel()]
+        got = {k: torch.empty(nb, dtype=torch.uint8, device=dev) for k, nb in incoming_sizes.items()}
+        recvs = [(src, t) for (dst, src), t in got.items() if t.numel()]
+        self.t._batch(sends, recvs)
+        return got
+
+    def sum(self, values):
+        torch = self.t.torch
+        t = torch.tensor([float(sum(values))], dtype=torch.float64, device=self.t.comm_device)
+        self.t.dist.all_reduce(t, group=self.t.group)
+        return float(t.item())
+
+
+class IisphSlabs:
+    """MultiphaseSPHSolver::SolveIISPH (solver/MultiphaseSPHSolver.cpp:173-188; rounds: solver/sph_solver.cu:1409-1443)
+    on z-slabs: the slabs of `members` (SlabSolver objects built with iisph=True: all the slabs of the scene with a
+    LocalComm, or this process's one with a DistComm).
+
+    A step runs some 25 neighbour passes between two sorts, each reading what the pass before wrote at the
+    neighbours, so after every pass the fields it wrote are refreshed in the halo layers from the slab that owns
+    the particles: the sorted order of a slab is (y, layer, x, order key), so both slabs hold the particles of the
+    layers next to a cut in the same order, and a refresh is a gather on one side and a scatter on the other.  The
+    particle exchange after the integration is the WCSPH one with the pressure riding along (the relaxation of a step
+    starts from the pressures of the step before).  The mean of error[] that ends the pressure rounds is summed over
+    the particles each slab owns and then over the slabs.  Particle counts are known on the host here (one wait per
+    exchange and per round): the step is a dozen times longer than the WCSPH one."""
+
+    def __init__(self, members, comm, n_global, group, normal):
+        self.m, self.comm, self.n_global = list(members), comm, int(n_global)
+        for ss in self.m:
+            ss.backend.enable_iisph(group, normal)
+        self.rounds = []
+        self.lists = {}
+
+    def _neighbours(self, ss):
+        return [(sd, ss.rank + sd) for sd in (-1, 1) if 0 <= ss.rank + sd < ss.world]
+
+    def exchange(self):
+        counts, recs, extras, rb = {}, {}, {}, None
+        for ss in self.m:
+            with ss.backend.stream_ctx():
+                lay = ss.layout
+                kept, lost, out = ss.backend.pack_carry(ss.own, ss.held_layers, lay.held(ss.rank - 1),
+                                                        lay.held(ss.rank + 1), ss.record_cap)
+            ss.lost += lost
+            rb = ss.backend.record_bytes
+            for sd, peer in self._neighbours(ss):
+                r, x, n = out[sd]
+                counts[(ss.rank, peer)], recs[(ss.rank, peer)], extras[(ss.rank, peer)] = n, r, x
+                ss.sent_records += n
+        for ss in self.m:
+            ss.backend.synchronize()
+        inc = self.comm.swap_counts(counts)
+        got_r = self.comm.swap_bytes(recs, {k: n * rb for k, n in inc.items()})
+        got_x = self.comm.swap_bytes(extras, {k: n * self.m[0].backend.real_bytes for k, n in inc.items()})
+        for ss in self.m:
+            with ss.backend.stream_ctx():
+                for sd, peer in self._neighbours(ss):  # fixed order: left neighbour first
+                    k = (ss.rank, peer)
+                    ss.backend.unpack_carry(got_r[k], got_x[k], inc[k])
+
+    def _after_sort(self):
+        """the lists of the layers next to the cuts: what a slab owns there, and its copies of what the neighbour owns"""
+        edge_counts = {}
+        for ss in self.m:
+            h = ss.halo
+            with ss.backend.stream_ctx():
+                for sd, peer in self._neighbours(ss):
+                    if sd < 0:
+                        edge, halo = (ss.own[0], min(ss.own[0] + h, ss.own[1])), (ss.own[0] - h, ss.own[0])
+                    else:
+                        edge, halo = (max(ss.own[1] - h, ss.own[0]), ss.own[1]), (ss.own[1], ss.own[1] + h)
+                    self.lists[(ss.rank, sd, "edge")] = ss.backend.layer_list(*edge)
+                    self.lists[(ss.rank, sd, "halo")] = ss.backend.layer_list(*halo)
+                    edge_counts[(ss.rank, peer)] = int(self.lists[(ss.rank, sd, "edge")].shape[0])
+        inc = self.comm.swap_counts(edge_counts)
+        for ss in self.m:
+            for sd, peer in self._neighbours(ss):
+                mine = int(self.lists[(ss.rank, sd, "halo")].shape[0])
+                if inc[(ss.rank, peer)] != mine:
+                    raise RuntimeError(f"slab {ss.rank}: {mine} halo copies of the layers slab {peer} owns next to the cut, "
+                                       f"but that slab holds {inc[(ss.rank, peer)]} particles there")
+
+    def refresh(self, fields):
+        out, sizes = {}, {}
+        for ss in self.m:
+            with ss.backend.stream_ctx():
+                for sd, peer in self._neighbours(ss):
+                    out[(ss.rank, peer)] = ss.backend.gather(fields, self.lists[(ss.rank, sd, "edge")])
+                    sizes[(ss.rank, peer)] = ss.backend.field_bytes(fields, int(self.lists[(ss.rank, sd, "halo")].shape[0]))
+        for ss in self.m:
+            ss.backend.synchronize()
+        got = self.comm.swap_bytes(out, sizes)
+        for ss in self.m:
+            with ss.backend.stream_ctx():
+                for sd, peer in self._neighbours(ss):
+                    ss.backend.scatter(fields, self.lists[(ss.rank, sd, "halo")], got[(ss.rank, peer)])
+
+    def _each(self, name):
+        for ss in self.m:
+            with ss.backend.stream_ctx():
+                getattr(ss.backend, name)()
+
+    def setup(self):
+        """SetupIISPH (solver/MultiphaseSPHSolver.cpp:850-860): sort, factor, rigid particle volumes"""
+        self.exchange()  # hands out the halo copies
+        self._each("setup_iisph")
+        self._after_sort()
+        self.refresh(["density", "dii", "restDensity"])
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            self._each("iisph_npf")
+            self.refresh(["v_star"])
+            self._each("iisph_predict_density")
+            last, rounds = np.float32(0.0), 0
+            for _it in range(10):  # "temp 10", solver/sph_solver.cu:1416
+                self._each("iisph_calc_dijpjl")
+                self.refresh(["dijpjl"])
+                self._each("iisph_calc_new_pressure")
+                self.refresh(["pressure"])
+                total = self.comm.sum([ss.backend.owned_error_sum(ss.own) for ss in self.m])
+                mean = np.float32(total / self.n_global)
+                rounds += 1
+                if abs(float(mean)) < 1e-6 or abs(float(np.float32(mean - last))) < 1e-6:  # :1440
+                    break
+                last = mean
+            self.rounds.append(rounds)
+            self._each("iisph_update")
+            self.exchange()
+            self._each("sort")
+            self._each("iisph_factor")
+            self._after_sort()
+            self.refresh(["density", "dii"])
 
 
 def derive_grid(P):

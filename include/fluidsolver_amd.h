@@ -391,6 +391,40 @@ int fsa_slab_export_owned(fsa_solver *s, const int own[2], void *d_records, int 
 /* Appends `count` records from device memory (written by a neighbour's fsa_slab_pack). */
 int fsa_slab_unpack(fsa_solver *s, const void *d_records, int count);
 
+/* ---- the IISPH step on z-slabs ------------------------------------------------------------------------------
+ *
+ * MultiphaseSPHSolver::SolveIISPH (solver/MultiphaseSPHSolver.cpp:173-188; the pressure rounds:
+ * solver/sph_solver.cu:1409-1443) runs some 25 neighbour passes between two sorts, each reading what the pass
+ * before wrote at the neighbours: a halo of copies goes stale after every pass.  On slabs the driver therefore
+ * refreshes, after each pass, the fields that pass wrote for the particles in the halo layers from the slab that
+ * owns them, with the calls below (no counterpart in the reference, which runs on one device).  The sorted order
+ * of a slab solver is (y, layer, x, order key), so two solvers that both hold a range of layers hold its in-grid
+ * particles in the same order: fsa_slab_layer_indices lists their sorted positions, the owner gathers a field
+ * through its list, the neighbour scatters the buffer through its own.  The stop test of the pressure rounds needs
+ * the mean of error[] over the whole scene: fsa_slab_owned_sum gives a slab's part of the sum.
+ */
+/* Prepares a slab solver for the fsa_iisph_* calls: allocates the arrays of that step, makes fsa_slab_pack_carry /
+ * fsa_slab_unpack_carry available, and hands over group[] and normal[] (cfloat3 layout, in the solver's precision) of
+ * the WHOLE scene, indexed by the global unique ids the solver's particles carry (n_global of them). */
+int fsa_slab_enable_iisph(fsa_solver *s, int n_global, const int *group, const void *normal3);
+/* fsa_slab_pack / fsa_slab_unpack that also carry pressure[] (the relaxation of a step starts from the pressures
+ * of the step before): the pressure of each record goes to d_extra_left / d_extra_right (cap_left / cap_right
+ * reals), slot for slot beside the records, and comes in through d_extras likewise. */
+int fsa_slab_pack_carry(fsa_solver *s, const int own[2], const int keep[2], const int left[2], const int right[2],
+                        void *d_send_left, void *d_extra_left, int cap_left, void *d_send_right, void *d_extra_right,
+                        int cap_right, int counts[4]);
+int fsa_slab_unpack_carry(fsa_solver *s, const void *d_records, const void *d_extras, int count);
+/* Sorted positions (ascending) of the in-grid particles in the global cell layers [layer_lo, layer_hi), which
+ * must be layers this solver holds, into the device array d_idx (cap ints); needs a sorted state.  Synchronises. */
+int fsa_slab_layer_indices(fsa_solver *s, int layer_lo, int layer_hi, int *d_idx, int cap, int *count);
+/* d_out[e] = field[d_idx[e]] / field[d_idx[e]] = d_in[e], device buffers; fields: density, pressure, restDensity,
+ * error (one real per particle), v_star, dii, dijpjl (three).  Queued on the solver's stream. */
+int fsa_slab_gather_field(fsa_solver *s, const char *name, const int *d_idx, int count, void *d_out);
+int fsa_slab_scatter_field(fsa_solver *s, const char *name, const int *d_idx, int count, const void *d_in);
+/* Sum (in double) of a scalar field over the particles this solver owns: cell layer in [own[0], own[1]) at the
+ * last sort, or outside the grid.  Synchronises. */
+int fsa_slab_owned_sum(fsa_solver *s, const char *name, const int own[2], double *sum);
+
 /* ---- z-slab groups: the whole slab step, exchange included, without a host round trip ------------------
  *
  * Replaces the step loop of main.cpp:11-19 -> MultiphaseSPHSolver::Step (solver/MultiphaseSPHSolver.cpp:199-217)

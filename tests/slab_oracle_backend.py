@@ -77,7 +77,8 @@ class OracleSlabBackend:
         return np.where(h == GRID_UNDEF, -1, (h // self.gres[0]) % self.gres[2])
 
     # -- exchange ---------------------------------------------------------------------------------
-    def pack(self, own, keep, left, right, buf_left, cap_left, buf_right, cap_right):
+    def _classify(self, own, keep, left, right):
+        """masks (stays, goes left, goes right, lost) over the present arrays: the rule of fsa_slab_pack"""
         n = self.n
         if self.sorted_hash is None:
             owned = np.ones(n, bool)
@@ -99,19 +100,26 @@ class OracleSlabBackend:
         l = owned & np.where(inside, (now >= left[0]) & (now < left[1]), filed < lo)
         r = owned & np.where(inside, (now >= right[0]) & (now < right[1]), filed >= hi)
         lost = owned & inside & ~k & ~l & ~r
+        return k, l, r, lost
+
+    def _records(self, mask):
+        rec = np.zeros(int(mask.sum()), RECORD)
+        rec["posType"][:, :3] = self.a["pos"][mask]
+        rec["posType"][:, 3] = self.a["type"][mask].view(np.float32)
+        rec["velMass"][:, :3] = self.a["vel"][mask]
+        rec["velMass"][:, 3] = self.a["mass"][mask]
+        rec["orderKey"] = self.key[mask]
+        rec["restDensity"] = self.a["restDensity"][mask]
+        rec["uniqueId"] = self.a["uniqueId"][mask]
+        return rec
+
+    def pack(self, own, keep, left, right, buf_left, cap_left, buf_right, cap_right):
+        k, l, r, lost = self._classify(own, keep, left, right)
         for mask, buf, cap in ((l, buf_left, cap_left), (r, buf_right, cap_right)):
             m = int(mask.sum())
             assert m <= cap, "send buffer too small"
-            rec = np.zeros(m, RECORD)
-            rec["posType"][:, :3] = self.a["pos"][mask]
-            rec["posType"][:, 3] = self.a["type"][mask].view(np.float32)
-            rec["velMass"][:, :3] = self.a["vel"][mask]
-            rec["velMass"][:, 3] = self.a["mass"][mask]
-            rec["orderKey"] = self.key[mask]
-            rec["restDensity"] = self.a["restDensity"][mask]
-            rec["uniqueId"] = self.a["uniqueId"][mask]
             if m:
-                buf.numpy()[:m * RECORD.itemsize] = rec.view(np.uint8).reshape(-1)
+                buf.numpy()[:m * RECORD.itemsize] = self._records(mask).view(np.uint8).reshape(-1)
         self.a = {name: v[k] for name, v in self.a.items()}
         self.key = self.key[k]
         self.sorted_hash = None
@@ -182,3 +190,136 @@ class OracleSlabBackend:
 
     def global_layer_of_sorted(self):
         return self._layer_of_hash(self.sorted_hash)
+
+
+IISPH_FIELD_WIDTH = {"density": 1, "pressure": 1, "restDensity": 1, "v_star": 3, "dii": 3, "dijpjl": 3}
+
+
+class OracleIisphSlabBackend(OracleSlabBackend):
+    """the same stand-in for the IISPH step on slabs (fluidsolver_amd.slabs.IisphSlabs): between a sort and the next
+    exchange the slab's particles live in one oracle state, on which the driver runs the oracle's stage functions;
+    the field refresh and the pressure that rides along with the records are restated in numpy"""
+    real_bytes = 4
+
+    def __init__(self, orc, params_dict, held, capacity):
+        super().__init__(orc, params_dict, held, capacity)
+        P = params_dict
+        self.p.surface_tension = P.get("surface_tension", 0.0)
+        self.p.boundary_friction = P.get("boundary_friction", 0.0)
+        self.st = None
+        self.pressure = np.zeros(0, np.float32)
+        self.uid_sorted = None
+
+    def enable_iisph(self, group, normal):
+        self.group_g = np.asarray(group, np.int32)
+        self.normal_g = np.asarray(normal, np.float32).reshape(-1, 3)
+        self.pressure = np.zeros(self.n, np.float32)
+
+    def upload(self, sub):
+        super().upload(sub)
+        self.pressure = np.zeros(self.n, np.float32)
+
+    def _flush(self):
+        """the particles leave the live state (after the integration, before the exchange)"""
+        if self.st is None:
+            return
+        for k in ("pos", "vel", "type", "mass", "restDensity"):
+            self.a[k] = self.st[k].copy()
+        self.a["uniqueId"] = self.uid_sorted
+        self.pressure = self.st["pressure"].copy()
+        self.st.close()
+        self.st = None
+
+    def pack_carry(self, own, keep, left, right, cap):
+        self._flush()
+        k, l, r, lost = self._classify(own, keep, left, right)
+        out = {}
+        for side, mask, rng in ((-1, l, left), (1, r, right)):
+            if rng[1] > rng[0]:
+                m = int(mask.sum())
+                assert m <= cap, "send buffer too small"
+                rec = self._records(mask).view(np.uint8).reshape(-1).copy()
+                out[side] = (torch.from_numpy(rec), torch.from_numpy(self.pressure[mask].copy().view(np.uint8)), m)
+        self.a = {name: v[k] for name, v in self.a.items()}
+        self.key = self.key[k]
+        self.pressure = self.pressure[k]
+        self.sorted_hash = None
+        return int(k.sum()), int(lost.sum()), out
+
+    def unpack_carry(self, records, extras, count):
+        if count:
+            self.unpack(records, count)
+            self.pressure = np.concatenate([self.pressure, extras.numpy().view(np.float32)[:count]])
+
+    def sort(self):
+        self._flush()
+        order = np.argsort(self.key.astype(np.uint64), kind="stable")
+        self.a = {name: v[order] for name, v in self.a.items()}
+        uid = self.a["uniqueId"]
+        st = self.orc.new_state(self.n, self.num_cells)
+        load = {k: self.a[k] for k in ("pos", "vel", "type", "mass", "restDensity")}
+        load.update(group=self.group_g[uid], normal=self.normal_g[uid], pressure=self.pressure[order])
+        st.load(load)
+        st.sort_particles(self.p)
+        h = st["particleHash"].copy()
+        self.uid_sorted = uid[st["uniqueId"]]
+        n = len(h)
+        first = np.ones(n, bool)
+        first[1:] = h[1:] != h[:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(n), 0))
+        self.key = (h.astype(np.int64) << 32) | (np.arange(n) - start)
+        self.sorted_hash = h
+        self.st = st
+
+    def setup_iisph(self):
+        self.sort()
+        self.st.iisph_factor(self.p)
+        self.st.rigid_particle_volume(self.p)
+
+    def iisph_factor(self): self.st.iisph_factor(self.p)
+    def iisph_npf(self): self.st.non_pressure_force_multiphase(self.p)
+    def iisph_predict_density(self): self.st.iisph_predict_density(self.p)
+    def iisph_calc_dijpjl(self): self.st.iisph_calc_dijpjl(self.p)
+    def iisph_calc_new_pressure(self): self.st.iisph_calc_new_pressure(self.p)
+    def iisph_update(self): self.st.iisph_update(self.p)
+
+    def layer_list(self, lo, hi):
+        layer = self._layer_of_hash(self.sorted_hash)
+        return torch.from_numpy(np.nonzero((layer >= lo) & (layer < hi))[0].astype(np.int32))
+
+    def gather(self, fields, idx):
+        i = idx.numpy()
+        parts = [np.ascontiguousarray(self.st[f][i]).view(np.uint8).reshape(-1) for f in fields]
+        return torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+
+    def scatter(self, fields, idx, data):
+        i, raw, at = idx.numpy(), data.numpy(), 0
+        for f in fields:
+            w = IISPH_FIELD_WIDTH[f]
+            nb = len(i) * w * 4
+            vals = raw[at:at + nb].view(np.float32)
+            self.st[f][i] = vals.reshape(-1, 3) if w == 3 else vals
+            at += nb
+        assert at == len(raw), "field refresh: the two slabs disagree on how many particles the layers hold"
+
+    def field_bytes(self, fields, count):
+        return count * sum(IISPH_FIELD_WIDTH[f] for f in fields) * 4
+
+    def owned_error_sum(self, own):
+        layer = self._layer_of_hash(self.sorted_hash)
+        m = (layer < 0) | ((layer >= own[0]) & (layer < own[1]))
+        return float(self.st["error"][m].astype(np.float64).sum())
+
+    def get(self, name):
+        if name == "particleHash":
+            return self.sorted_hash
+        if name == "uniqueId":
+            return self.uid_sorted if self.st is not None else self.a["uniqueId"]
+        if self.st is not None:
+            return self.st[name].copy()
+        return self.pressure if name == "pressure" else self.a[name]
+
+    def close(self):
+        if self.st is not None:
+            self.st.close()
+            self.st = None

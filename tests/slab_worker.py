@@ -66,7 +66,31 @@ def drift_scene():
     return sc
 
 
-SCENES = {"dam": test_scene, "ddam": ddam_scene, "drift": drift_scene}
+def itank_scene():
+    """a column of fluid in a tank of TYPE_RIGID particles (the kind of scene the IISPH step runs), long in z, with
+    noise on positions and velocities: particles cross the slab cuts, and the walls are part of every slab"""
+    from fluidsolver_amd import scenes
+    sc = scenes.iisph_tank(8, 10, 26)
+    rng = np.random.Generator(np.random.PCG64(79))
+    fl = np.asarray(sc["type"]) == 0
+    pos, vel = np.array(sc["pos"], np.float32), np.array(sc["vel"], np.float32)
+    pos[fl] += rng.uniform(-0.15, 0.15, (int(fl.sum()), 3)).astype(np.float32) * np.float32(0.005)
+    vel[fl] = rng.uniform(-1.0, 1.0, (int(fl.sum()), 3)).astype(np.float32) * np.float32([0.3, 0.3, 1.5])
+    sc["pos"], sc["vel"] = pos, vel
+    return sc
+
+
+SCENES = {"dam": test_scene, "ddam": ddam_scene, "drift": drift_scene, "itank": itank_scene}
+
+
+def owned_iisph(ss):
+    """what a slab owns after IISPH steps (each ends with the sort and the density of the next step)"""
+    b = ss.backend
+    layer = b.global_layer_of_sorted()
+    m = ((layer >= ss.own[0]) & (layer < ss.own[1])) | (layer < 0)
+    out = {k: np.asarray(b.get(k))[m] for k in ("pos", "vel", "density", "pressure", "uniqueId", "type")}
+    out["hash_layer"] = layer[m]
+    return out
 
 
 def main():
@@ -80,6 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--recut-at", type=int, default=0, help="re-cut the slabs after this many steps")
+    ap.add_argument("--mode", choices=["wcsph", "iisph"], default="wcsph")
     a = ap.parse_args()
 
     import torch
@@ -90,11 +115,12 @@ def main():
     sc = SCENES[a.scene]()
     if a.backend == "oracle":
         from oracle.orc import Oracle
-        from slab_oracle_backend import OracleSlabBackend
+        from slab_oracle_backend import OracleIisphSlabBackend, OracleSlabBackend
         orc = Oracle("f32")
         orc.set_threads(2)
         device = torch.device("cpu")
-        factory = lambda P, held, cap: OracleSlabBackend(orc, P, held, cap)  # noqa: E731
+        cls = OracleIisphSlabBackend if a.mode == "iisph" else OracleSlabBackend
+        factory = lambda P, held, cap: cls(orc, P, held, cap)  # noqa: E731
     else:
         device = torch.device("cuda", 0)
         factory = lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, a.variant)  # noqa: E731
@@ -106,6 +132,19 @@ def main():
         cuts = [0] + [3 * (r + 1) for r in range(a.world - 1)] + [gz]
     if a.scene == "drift" and not a.recut_at:
         cuts = DRIFT_CUTS[a.world]
+    if a.mode == "iisph":
+        ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts, exchange_buffers=False)
+        team = slabs.IisphSlabs([ss], slabs.DistComm(tr), len(sc["pos"]), sc["group"], sc["normal"])
+        team.setup()
+        team.step(a.steps)
+        out = owned_iisph(ss)
+        out.update(cuts=np.asarray(ss.layout.cuts), lost=np.asarray(ss.lost), sent=np.asarray(ss.sent_records),
+                   rounds=np.asarray(team.rounds))
+        np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **out)
+        ss.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts)
     if a.recut_at:
         ss.step(a.recut_at)

@@ -24,11 +24,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0, scene="dam"):
+def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0, scene="dam", mode="wcsph"):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "--rank", str(r), "--world",
                                str(world), "--port", str(port), "--out", str(out), "--backend", backend, "--steps",
-                               str(steps), "--variant", str(variant), "--recut-at", str(recut_at), "--scene", scene])
+                               str(steps), "--variant", str(variant), "--recut-at", str(recut_at), "--scene", scene,
+                               "--mode", mode])
              for r in range(world)]
     try:
         codes = [p.wait(timeout=timeout) for p in procs]
@@ -226,3 +227,48 @@ def test_windowed_scene_gives_each_rank_its_particles_of_the_whole_scene():
         assert sorted(a.backend.sub) == sorted(b.backend.sub)
         for k in a.backend.sub:
             assert np.array_equal(a.backend.sub[k], b.backend.sub[k]), k
+
+
+# ---- the IISPH step on slabs ---------------------------------------------------------------------------------
+def assert_same_iisph_bits(parts, ref):
+    uid = np.concatenate([p["uniqueId"] for p in parts])
+    order = np.argsort(uid, kind="stable")
+    ro = np.argsort(ref["uniqueId"], kind="stable")
+    assert np.array_equal(uid[order], ref["uniqueId"][ro]), "every particle must be owned by exactly one rank"
+    typ = np.concatenate([p["type"] for p in parts])[order]
+    for k in ("pos", "vel", "type", "pressure", "density"):
+        a, b = np.concatenate([p[k] for p in parts])[order], ref[k][ro]
+        if k == "density":  # (never written for TYPE_RIGID particles: whatever the array slot held before)
+            a, b = a[typ == 0], b[typ == 0]
+        assert np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes(), f"{k} differs from the undivided run"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_iisph_slab_run_equals_undivided_run(orc32, tmp_path, world):
+    """the step main.cpp runs (SolveIISPH) on slabs: a field refresh after every neighbour pass, the pressure riding
+    with the records, the stop test summed over the slabs; tank walls (TYPE_RIGID) in every slab.  Every owned
+    particle must carry the bits of the undivided oracle run, and the rounds must be the same in number"""
+    from slab_worker import SCENES
+    steps = 6
+    parts = run_ranks(world, "oracle", steps, tmp_path, scene="itank", mode="iisph")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    assert sum(int(p["sent"]) for p in parts) > 0
+    sc = SCENES["itank"]()
+    p, st = oracle_pair(orc32, sc)
+    st.sort_particles(p)
+    st.iisph_factor(p)
+    st.rigid_particle_volume(p)
+    rounds = []
+    for _ in range(steps):
+        st.non_pressure_force_multiphase(p)
+        st.iisph_predict_density(p)
+        rounds.append(st.iisph_solve_pressure(p, 10, mean_in_double=True)[0])
+        st.iisph_update(p)
+        st.sort_particles(p)
+        st.iisph_factor(p)
+    ref = {k: st[k].copy() for k in ("pos", "vel", "density", "pressure", "uniqueId", "type")}
+    st.close()
+    for part in parts:
+        assert part["rounds"].tolist() == rounds
+    assert max(rounds) > 1
+    assert_same_iisph_bits(parts, ref)
