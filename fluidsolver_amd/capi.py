@@ -33,6 +33,8 @@ EXPORTS = (
     "fsa_set_scene_has_rigid", "fsa_sort_particle_static",
     "fsa_slab_enable_iisph", "fsa_slab_pack_carry", "fsa_slab_unpack_carry", "fsa_slab_layer_indices",
     "fsa_slab_gather_field", "fsa_slab_scatter_field", "fsa_slab_owned_sum",
+    "fsa_slab_iisph_create_local", "fsa_slab_iisph_setup", "fsa_slab_iisph_step", "fsa_slab_iisph_stats",
+    "fsa_slab_iisph_destroy",
     "fsa_slab_group_create_local", "fsa_slab_group_unique_id", "fsa_slab_group_create_rccl", "fsa_slab_group_step",
     "fsa_slab_group_sync", "fsa_slab_group_rccl_loopback", "fsa_slab_group_destroy",
     "fsa_compute_density_alpha", "fsa_compute_non_pressure_force", "fsa_solve_density_stiff",
@@ -157,6 +159,12 @@ def load() -> C.CDLL:
         "fsa_slab_gather_field": [H, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p],
         "fsa_slab_scatter_field": [H, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p],
         "fsa_slab_owned_sum": [H, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)],
+        "fsa_slab_iisph_create_local": [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p)],
+        "fsa_slab_iisph_setup": [H], "fsa_slab_iisph_step": [H, C.c_int],
+        "fsa_slab_iisph_stats": [H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_int), C.c_int],
+        "fsa_slab_iisph_destroy": [H],
         "fsa_slab_group_create_local": [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                         C.POINTER(C.c_void_p)],
         "fsa_slab_group_unique_id": [C.c_char_p],
@@ -639,4 +647,38 @@ class SlabGroup:
         try:
             self.close()
         except Exception:  # noqa: BLE001
+            pass
+
+
+class SlabIisphTeam:
+    """fsa_slab_iisph_*: the IISPH step on slabs that all live in this process (the solvers must have been prepared
+    with Solver.slab_enable_iisph and hold the particles they own)."""
+
+    def __init__(self, solvers, cuts, halo, record_cap, n_global):
+        self.lib = load()
+        self.solvers = list(solvers)
+        arr = (C.c_void_p * len(self.solvers))(*[s._h for s in self.solvers])
+        self._h = C.c_void_p()
+        check(self.lib.fsa_slab_iisph_create_local(len(self.solvers), arr, (C.c_int * len(cuts))(*cuts), int(halo),
+                                                   int(record_cap), int(n_global), C.byref(self._h)))
+
+    def setup(self): check(self.lib.fsa_slab_iisph_setup(self._h))
+    def step(self, nsteps=1): check(self.lib.fsa_slab_iisph_step(self._h, int(nsteps)))
+
+    def stats(self, last_rounds=0):
+        """-> (steps, lost, records_sent, [rounds of the last `last_rounds` steps]); waits for the device"""
+        st, lo, se = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        r = (C.c_int * max(last_rounds, 1))()
+        check(self.lib.fsa_slab_iisph_stats(self._h, C.byref(st), C.byref(lo), C.byref(se), r, int(last_rounds)))
+        return st.value, lo.value, se.value, list(r)[:last_rounds]
+
+    def close(self):
+        if self._h:
+            self.lib.fsa_slab_iisph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
             pass

@@ -252,6 +252,13 @@ void MultiphaseSPHSolver::SetupIISPH() {
         for (int t = 0; t < maxtypenum; t++) dens[t] = densArr[t];
         check(fsa_set_volume_fractions(device, maxtypenum, dens, rows.data()), "fsa_set_volume_fractions");
         check(fsa_effective_mass(device), "EffectiveMass");
+        // several z-slabs under this one host program (slab_mode.cpp): the rest of the set-up runs on them
+        if (const char *slabs = std::getenv("FSA_SLABS"))
+            if (std::atoi(slabs) > 0) {
+                EnterSlabModeIISPH(std::atoi(slabs));
+                CopyPosColorFromDevice();
+                return;
+            }
         check(fsa_iisph_factor(device), "IISPHFactor");
         check(fsa_rigid_particle_volume(device), "RigidParticleVolume");
         CopyPosColorFromDevice();

@@ -62,6 +62,8 @@ std::vector<int> balanced_cuts(const std::vector<long long> &hist, int nranks, i
 void SPHSolver::LeaveSlabMode() {
     if (slab_group) fsa_slab_group_destroy(slab_group);
     slab_group = nullptr;
+    if (slab_team) fsa_slab_iisph_destroy(slab_team);
+    slab_team = nullptr;
     for (fsa_solver *s : slab_devices) fsa_destroy(s);
     slab_devices.clear();
 }
@@ -70,7 +72,7 @@ void SPHSolver::LeaveSlabMode() {
 // nslabs slabs and `device` is released.
 void SPHSolver::EnterSlabMode(int nslabs) {
     if (run_mode != SPH) {
-        std::fprintf(stderr, "FSA_SLABS: only the SPH (WCSPH) step runs on several slabs\n");
+        std::fprintf(stderr, "FSA_SLABS: only the SPH (WCSPH) and IISPH steps run on several slabs\n");
         std::exit(EXIT_FAILURE);
     }
     const int n = numParticles;
@@ -129,8 +131,18 @@ void SPHSolver::EnterSlabMode(int nslabs) {
         const int c = slab_cuts[r];
         widest = std::max(widest, pre[std::min(c + 2 * kHalo, gz)] - pre[std::max(c - 2 * kHalo, 0)]);
     }
-    const int capacity = (int)(most * 3 / 2 + outside + 4096);
-    const int record_cap = (int)(widest * 3 / 2 + 4096);
+    // head room over the fullest slab's present count: the slabs are not re-cut during a run, so a scene whose mass
+    // moves along z needs more (FSA_SLAB_HEADROOM, default 1.5; an outgrown slab ends the run with FSA_ERR_CAPACITY)
+    double headroom = 1.5;
+    if (const char *e = std::getenv("FSA_SLAB_HEADROOM")) headroom = std::max(1.0, std::atof(e));
+    const long long capacity64 = (long long)((double)most * headroom) + outside + 4096;
+    const long long record_cap64 = (long long)((double)widest * headroom) + 4096;
+    if (capacity64 > 2000000000LL || record_cap64 > 2000000000LL) {
+        std::fprintf(stderr, "FSA_SLABS=%d: a slab would hold %lld particles, more than one solver takes; use more slabs\n", nslabs,
+                     capacity64);
+        std::exit(EXIT_FAILURE);
+    }
+    const int capacity = (int)capacity64, record_cap = (int)record_cap64;
     int ndev = 1, dev0 = 0;
     if (const char *e = std::getenv("FSA_SLAB_DEVICES")) ndev = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("FSA_DEVICE")) dev0 = std::atoi(e);
@@ -165,16 +177,126 @@ void SPHSolver::EnterSlabMode(int nslabs) {
           "fsa_slab_group_create_local");
     std::printf("%d particles on %d z-slabs (cuts", n, nslabs);
     for (int c : slab_cuts) std::printf(" %d", c);
-    std::printf("), capacity %d each\n", capacity);
+    std::printf("), capacity %d each (head room %.2f: FSA_SLAB_HEADROOM)\n", capacity, headroom);
 }
 
-void SPHSolver::StepSlabs() { check(fsa_slab_group_step(slab_group, 1), "fsa_slab_group_step"); }
+// The IISPH step (what the reference's main.cpp runs) on nslabs z-slabs.  Called in the middle of SetupIISPH, with the
+// scene on `device` sorted once and the effective masses in place (solver/MultiphaseSPHSolver.cpp:855-856): that state
+// is cut into slabs, `device` is released, and the rest of the set-up (factors, rigid particle volumes: :857-858)
+// runs on the slabs.  A particle keeps its unique id; group and normal, which the step reads of a neighbour and which
+// never change, go to every slab as tables over all ids.
+void SPHSolver::EnterSlabModeIISPH(int nslabs) {
+    const int n = numParticles;
+    const int gz = hParam.gridres[2];
+    if (nslabs < 1 || gz < nslabs * (kHalo + 1)) {
+        std::fprintf(stderr, "FSA_SLABS=%d: %d cell layers cannot be cut into that many slabs of at least %d\n", nslabs, gz,
+                     kHalo + 1);
+        std::exit(EXIT_FAILURE);
+    }
+    vecf3 p((size_t)n), v((size_t)n);
+    vecf m((size_t)n), rd((size_t)n);
+    veci t((size_t)n), uid((size_t)n);
+    vecf4 col((size_t)n);
+    int got = 0;
+    check(fsa_readback_pos_color(device, p.data(), col.data(), &got), "fsa_readback_pos_color");
+    check(fsa_get_buffer(device, "vel", v.data(), (size_t)n * sizeof(cfloat3)), "get vel");
+    check(fsa_get_buffer(device, "type", t.data(), (size_t)n * sizeof(int)), "get type");
+    check(fsa_get_buffer(device, "mass", m.data(), (size_t)n * sizeof(float)), "get mass");
+    check(fsa_get_buffer(device, "restDensity", rd.data(), (size_t)n * sizeof(float)), "get restDensity");
+    check(fsa_get_buffer(device, "uniqueId", uid.data(), (size_t)n * sizeof(int)), "get uniqueId");
+    fsa_destroy(device);
+    device = nullptr;
+    slab_color.resize((size_t)n);
+    bool rigid = false;
+    for (int i = 0; i < n; i++) {
+        slab_color[(size_t)uid[i]] = col[i];
+        rigid |= t[i] == TYPE_RIGID;
+    }
+
+    veci layer((size_t)n);
+    std::vector<long long> hist((size_t)gz, 0);
+    long long outside = 0;
+    for (int i = 0; i < n; i++) {
+        layer[i] = cell_layer(p[i], hParam);
+        if (layer[i] >= 0) {
+            hist[layer[i]]++;
+        } else {
+            outside++;
+            layer[i] = outside_layer(p[i], hParam);
+        }
+    }
+    slab_cuts = nslabs > 1 ? balanced_cuts(hist, nslabs, kHalo + 1) : std::vector<int>{0, gz};
+    std::vector<long long> pre((size_t)gz + 1, 0);
+    for (int z = 0; z < gz; z++) pre[z + 1] = pre[z] + hist[z];
+    auto held = [&](int r, int out[2]) {
+        out[0] = std::max(slab_cuts[r] - kHalo, 0);
+        out[1] = std::min(slab_cuts[r + 1] + kHalo, gz);
+    };
+    long long most = 0, widest = 0;
+    for (int r = 0; r < nslabs; r++) {
+        int h[2];
+        held(r, h);
+        most = std::max(most, pre[h[1]] - pre[h[0]]);
+    }
+    for (int r = 1; r < nslabs; r++) {
+        const int c = slab_cuts[r];
+        widest = std::max(widest, pre[std::min(c + 2 * kHalo, gz)] - pre[std::max(c - 2 * kHalo, 0)]);
+    }
+    const long long capacity = most * 3 / 2 + outside + 4096, record_cap = widest * 3 / 2 + 4096;
+    if (capacity > 2000000000LL || record_cap > 2000000000LL) {
+        std::fprintf(stderr, "FSA_SLABS=%d: a slab would hold %lld particles, more than one solver takes; use more slabs\n", nslabs, capacity);
+        std::exit(EXIT_FAILURE);
+    }
+    int ndev = 1, dev0 = 0;
+    if (const char *e = std::getenv("FSA_SLAB_DEVICES")) ndev = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("FSA_DEVICE")) dev0 = std::atoi(e);
+    for (int r = 0; r < nslabs; r++) {
+        int h[2];
+        held(r, h);
+        fsa_params P = hParam;
+        P.slab_z0 = h[0];
+        P.slab_nz = h[1] - h[0];
+        fsa_solver *s = nullptr;
+        check(fsa_create(&P, FSA_PRECISION_F32, (int)capacity, dev0 + r % ndev, &s), "fsa_create (slab)");
+        slab_devices.push_back(s);
+        if (const char *e = std::getenv("FSA_VARIANT")) check(fsa_set_variant(s, std::atoi(e)), "fsa_set_variant");
+        vecf3 sp, sv;
+        vecf sm, srd;
+        veci st, sid;
+        for (int i = 0; i < n; i++) {
+            if (layer[i] < slab_cuts[r] || layer[i] >= slab_cuts[r + 1]) continue;
+            sp.push_back(p[i]);
+            sv.push_back(v[i]);
+            sm.push_back(m[i]);
+            srd.push_back(rd[i]);
+            st.push_back(t[i]);
+            sid.push_back(uid[i]);
+        }
+        check(fsa_upload(s, (int)sp.size(), sp.data(), sv.data(), nullptr, nullptr, st.data(), nullptr, sid.data(),
+                         sm.data(), srd.data()),
+              "fsa_upload (slab)");
+        check(fsa_set_scene_has_rigid(s, rigid ? 1 : 0), "fsa_set_scene_has_rigid");
+        check(fsa_slab_enable_iisph(s, n, group.data(), normal.data()), "fsa_slab_enable_iisph");
+    }
+    check(fsa_slab_iisph_create_local(nslabs, slab_devices.data(), slab_cuts.data(), kHalo, (int)record_cap, n, &slab_team),
+          "fsa_slab_iisph_create_local");
+    check(fsa_slab_iisph_setup(slab_team), "fsa_slab_iisph_setup");
+    std::printf("%d particles on %d z-slabs (cuts", n, nslabs);
+    for (int c : slab_cuts) std::printf(" %d", c);
+    std::printf("), capacity %lld each, IISPH step\n", capacity);
+}
+
+void SPHSolver::StepSlabs() {
+    if (slab_team) check(fsa_slab_iisph_step(slab_team, 1), "fsa_slab_iisph_step");
+    else check(fsa_slab_group_step(slab_group, 1), "fsa_slab_group_step");
+}
 
 // Positions and colours of all slabs in the order a single solver would hold them: ascending global cell, inside a
 // cell the slab's own order, out-of-grid particles last.
 void SPHSolver::CopyPosColorFromSlabs() {
     fsa_slab_group_stats st{};
-    check(fsa_slab_group_sync(slab_group, &st), "fsa_slab_group_sync");
+    if (slab_team) check(fsa_slab_iisph_stats(slab_team, nullptr, &st.lost, nullptr, nullptr, 0), "fsa_slab_iisph_stats");
+    else check(fsa_slab_group_sync(slab_group, &st), "fsa_slab_group_sync");
     struct Item {
         unsigned long long cell;
         cfloat3 pos;

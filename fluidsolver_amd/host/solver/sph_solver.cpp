@@ -60,7 +60,7 @@ void SPHSolver::CopyParam2Device() { check(fsa_copy_param_to_device(device, &hPa
 
 // CopyPosColorFromDevice, solver/sph_solver.cpp:35-38: current device order.
 void SPHSolver::CopyPosColorFromDevice() {
-    if (slab_group) {
+    if (slab_group || slab_team) {
         CopyPosColorFromSlabs();
         return;
     }
@@ -70,7 +70,7 @@ void SPHSolver::CopyPosColorFromDevice() {
 
 // CopySimulationDataFromDevice (solver/MultiphaseSPHSolver.cpp:29-46): everything the text dump prints.
 void SPHSolver::CopySimulationDataFromDevice() {
-    if (slab_group) {
+    if (slab_group || slab_team) {
         std::fprintf(stderr, "dumps need velocities, groups and v_star in one place: not available with FSA_SLABS\n");
         std::exit(EXIT_FAILURE);
     }
@@ -122,7 +122,7 @@ void SPHSolver::SolveIISPH() {
 
 // Step, solver/sph_solver.cpp:129-142 and solver/MultiphaseSPHSolver.cpp:199-217
 void SPHSolver::Step() {
-    if (numParticles > 0 && slab_group) {
+    if (numParticles > 0 && (slab_group || slab_team)) {
         StepSlabs();
     } else if (numParticles > 0) {
         switch (run_mode) {

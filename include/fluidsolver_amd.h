@@ -425,6 +425,27 @@ int fsa_slab_scatter_field(fsa_solver *s, const char *name, const int *d_idx, in
  * last sort, or outside the grid.  Synchronises. */
 int fsa_slab_owned_sum(fsa_solver *s, const char *name, const int own[2], double *sum);
 
+/* The whole of that for slabs that all belong to solvers of THIS process (one host program driving a node, as the
+ * reference's main.cpp drives one GPU): replaces SetupIISPH / SolveIISPH (solver/MultiphaseSPHSolver.cpp:850-860,
+ * 173-188) for a scene cut into z-slabs.  The solvers: fp32 or fp64 slab solvers prepared by fsa_slab_enable_iisph,
+ * each holding the layers [cuts[r] - halo, cuts[r+1] + halo) (clipped to the grid) and, at this point, the particles
+ * of the layers it owns, as uploaded (unique ids of the whole scene, n_global of them).  fsa_slab_iisph_setup hands
+ * out the halo copies, sorts, and computes the factors and rigid particle volumes; fsa_slab_iisph_step runs whole
+ * steps (each ends, like SolveIISPH, with the sort and the factors of the next).  Particle counts are kept on the
+ * host: a step waits for the device a few dozen times (it is a dozen times longer than the WCSPH step).  Results for
+ * every particle equal the single solver's bit for bit, with the same number of pressure rounds. */
+typedef struct fsa_slab_iisph fsa_slab_iisph;
+int fsa_slab_iisph_create_local(int world, fsa_solver **solvers, const int *cuts /* world + 1 */, int halo,
+                                int record_cap, int n_global, fsa_slab_iisph **out);
+int fsa_slab_iisph_setup(fsa_slab_iisph *t);
+int fsa_slab_iisph_step(fsa_slab_iisph *t, int nsteps);
+/* Waits for the queued work; any pointer may be NULL.  rounds[0 .. rounds_cap): pressure rounds of the last
+ * rounds_cap steps, oldest first (0 where there was no such step). */
+int fsa_slab_iisph_stats(fsa_slab_iisph *t, long long *steps, long long *lost, long long *records_sent, int *rounds,
+                         int rounds_cap);
+/* The solvers live on. */
+int fsa_slab_iisph_destroy(fsa_slab_iisph *t);
+
 /* ---- z-slab groups: the whole slab step, exchange included, without a host round trip ------------------
  *
  * Replaces the step loop of main.cpp:11-19 -> MultiphaseSPHSolver::Step (solver/MultiphaseSPHSolver.cpp:199-217)

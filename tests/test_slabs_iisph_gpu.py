@@ -50,6 +50,31 @@ def test_iisph_on_local_slabs_equals_plain_solver(world, variant):
         ss.close()
 
 
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_library_team_equals_plain_solver(world):
+    """the same step driven inside the library (fsa_slab_iisph_*: what the host program uses for FSA_SLABS=N with
+    the IISPH step), refreshes ordered by events instead of host waits"""
+    sc = SCENES["itank"]()
+    ref, rounds = plain_iisph_run(sc, STEPS, 3)
+    ranks = [slabs.SlabSolver(sc, r, world, None, lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, 3),
+                              exchange_buffers=False) for r in range(world)]
+    for ss in ranks:
+        ss.backend.enable_iisph(sc["group"], sc["normal"])
+    team = capi.SlabIisphTeam([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                              max(ss.record_cap for ss in ranks), len(sc["pos"]))
+    team.setup()
+    team.step(2)
+    team.step(STEPS - 2)
+    steps, lost, sent, got_rounds = team.stats(STEPS)
+    assert steps == STEPS and lost == 0 and got_rounds == rounds
+    if world > 1:
+        assert sent > 0
+    assert_same_iisph_bits([owned_iisph(ss) for ss in ranks], ref)
+    team.close()
+    for ss in ranks:
+        ss.close()
+
+
 def test_iisph_two_ranks_over_gloo_equal_plain_solver(tmp_path):
     parts = run_ranks(2, "hip", STEPS, tmp_path, variant=3, scene="itank", mode="iisph")
     assert sum(int(p["lost"]) for p in parts) == 0
