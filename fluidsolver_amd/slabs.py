@@ -587,6 +587,61 @@ class SlabSolver:
         self.backend.close()
 
 
+def rebalance_local(ranks):
+    """SlabSolver.rebalance for slabs that all live in this process (a rehearsal of N ranks on one GPU, or one host
+    program driving a node): every slab exports what it owns, the cuts are balanced afresh on the summed layer
+    histogram, every slab gets a new solver for its new layers and the records that now belong to it.  Order keys
+    travel along, so the run stays bit-identical.  Returns True if the cuts changed."""
+    import torch
+    world = len(ranks)
+    if world == 1:
+        return False
+    recs, filed, hist, n_outside = [], [], 0, 0
+    gz = ranks[0].gridres[2]
+    for ss in ranks:
+        with ss.backend.stream_ctx():
+            b, rb = ss.backend, ss.backend.record_bytes
+            cap = max(b.n, 1)
+            buf = b.make_buffer(cap)
+            cnt = b.export_owned(ss.own, buf, cap)
+            rec = buf[:cnt * rb].view(cnt, rb)
+            layer = ss._record_layers(rec)
+            hist = hist + torch.bincount(layer[layer >= 0], minlength=gz).cpu().numpy()
+            n_outside += int((layer < 0).sum().item())
+            recs.append(rec)
+            filed.append(ss._record_filed)
+            b.synchronize()
+    cuts = balanced_cuts(hist, world, ranks[0].halo + 1)
+    if cuts == ranks[0].layout.cuts:
+        return False
+    bounds = torch.tensor(cuts[1:-1], dtype=torch.int64, device=filed[0].device)
+    owners = [torch.bucketize(f, bounds, right=True) for f in filed]
+    pre = np.concatenate([[0], np.cumsum(hist)])
+    layout = SlabLayout(gz, cuts, ranks[0].halo)
+    held_counts = [pre[layout.held(r)[1]] - pre[layout.held(r)[0]] for r in range(world)]
+    capacity = int(max(held_counts) * ranks[0].slack) + n_outside + 4096
+    widest = max(int(hist[max(c - 2 * layout.halo, 0):c + 2 * layout.halo].sum()) for c in cuts[1:-1])
+    record_cap = int(widest * ranks[0].slack) + 4096
+    for ss in ranks:
+        ss.backend.close()
+    for ss in ranks:
+        ss.layout = layout
+        ss.own, ss.held_layers = layout.own(ss.rank), layout.held(ss.rank)
+        ss.capacity, ss.record_cap = capacity, record_cap
+        ss.backend = ss.factory(ss.params, ss.held_layers, capacity)
+        ss.backend.set_scene_has_rigid(ss.has_rigid)
+        ss.backend.set_owned(ss.own)
+        rb = ss.backend.record_bytes
+        with ss.backend.stream_ctx():
+            for src in range(world):  # in the order of the ranks the records come from
+                t = recs[src][owners[src] == ss.rank].reshape(-1).contiguous()
+                if t.numel():
+                    ss.backend.unpack(t, t.numel() // rb)
+            ss.backend.synchronize()
+        ss.recuts += 1
+    return True
+
+
 # ------------------------------------------------------------------------------------------------
 # the IISPH step on slabs
 # ------------------------------------------------------------------------------------------------

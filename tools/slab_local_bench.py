@@ -13,26 +13,81 @@ ap.add_argument("--steps", type=int, default=20); ap.add_argument("--spinup", ty
 ap.add_argument("--dims", type=int, nargs=3, default=None, help="dam break of nx ny nz particles instead of --scene")
 ap.add_argument("--check", action="store_true", help="compare every owned particle with a plain single-solver run, bit for bit")
 ap.add_argument("--show", type=int, default=-1, help="slab whose kernel times are printed (default: the middle one)")
+ap.add_argument("--recut-every", type=int, default=0, help="balance the cuts afresh every so many steps")
+ap.add_argument("--lopsided", action="store_true", help="start from cuts that put most particles into the first slabs")
+ap.add_argument("--shift-cuts", type=int, default=0, help="start from the balanced cuts moved by this many layers")
 a = ap.parse_args()
 if a.dims:
     from fluidsolver_amd import scenes
     sc = scenes.dam_break(*a.dims)
 else:
     sc = bench.build_scene(a.scene, 0.0)
+cuts0 = None
+if a.lopsided:
+    gz = slabs.derive_grid(sc["params"])["gridres"][2]
+    cuts0 = [0] + [gz // 2 + 3 * r for r in range(a.world - 1)] + [gz]
+if a.shift_cuts:
+    geo = slabs.derive_grid(sc["params"])
+    lay = slabs.cell_layer_host(np.asarray(sc["pos"], np.float32), geo["vmin"], geo["vmax"], geo["dx"], geo["gridres"])
+    bal = slabs.balanced_cuts(np.bincount(lay[lay >= 0], minlength=geo["gridres"][2]), a.world)
+    cuts0 = [bal[0]] + [c + a.shift_cuts for c in bal[1:-1]] + [bal[-1]]
 ranks = [slabs.SlabSolver(sc, r, a.world, None, lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, 3),
-                          exchange_buffers=False) for r in range(a.world)]
-g = capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
-                         max(ss.record_cap for ss in ranks))
-g.step(a.spinup); g.sync()
+                          exchange_buffers=False, cuts=cuts0) for r in range(a.world)]
+
+
+def make_group():
+    return capi.SlabGroup.local([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                                max(ss.record_cap for ss in ranks))
+
+
+g = make_group()
+state = {"done": 0, "sent": 0, "lost": 0, "recuts": 0, "imbalance": []}
+
+
+def run(nsteps, timed=False):
+    global g
+    left = nsteps
+    while left > 0:
+        k = left
+        if a.recut_every:
+            k = min(k, a.recut_every - state["done"] % a.recut_every)
+        g.step(k)
+        left -= k
+        state["done"] += k
+        if a.recut_every and state["done"] % a.recut_every == 0 and left > 0:
+            st = g.sync()
+            state["sent"] += int(st.records_sent); state["lost"] += int(st.lost)
+            g.close()
+            held = [ss.backend.n for ss in ranks]
+            if slabs.rebalance_local(ranks):
+                state["recuts"] += 1
+            state["imbalance"].append({"step": state["done"], "held_before": held, "held_after": [ss.backend.n for ss in ranks],
+                                       "cuts": list(ranks[0].layout.cuts)})
+            if timed:
+                for ss in ranks:
+                    ss.backend.solver.timing_enable(True); ss.backend.solver.timing_reset()
+            g = make_group()
+
+
+run(a.spinup); g.sync()
 show = a.show if a.show >= 0 else a.world // 2
 for ss in ranks:
     ss.backend.solver.timing_enable(True); ss.backend.solver.timing_reset()
+sent0 = state["sent"]
 t0 = time.perf_counter()
-g.step(a.steps); st = g.sync()
+run(a.steps, timed=True); st = g.sync()
 wall = time.perf_counter() - t0
+state["sent"] += int(st.records_sent); state["lost"] += int(st.lost)
 res = {"world": a.world, "cuts": ranks[0].layout.cuts, "ms_per_step_all_slabs": wall / a.steps * 1e3,
        "ms_per_step_per_slab": wall / a.steps * 1e3 / a.world, "particles_held": [ss.backend.n for ss in ranks],
-       "lost": int(st.lost)}
+       "lost": state["lost"], "scene": a.scene, "steps": a.steps, "spinup": a.spinup, "recut_every": a.recut_every,
+       "recuts": state["recuts"], "records_sent_per_step": (state["sent"] - sent0) / max(a.steps, 1)}
+held = np.array(res["particles_held"], float)
+res["max_over_mean_particles_held"] = float(held.max() / held.mean())
+if state["imbalance"]:
+    res["recut_log"] = state["imbalance"]
+if a.recut_every:
+    res["ms_per_step_all_slabs_note"] = "wall time includes the re-cuts (export, new solvers, upload)"
 kt = ranks[show].backend.solver.timing_read()
 res["slab"] = show
 res["kernels_ms"] = {k: round(ms / c, 4) for k, (c, ms) in kt.items() if c}
