@@ -12,7 +12,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfluidsolver_amd.so")
+# (FSA_LIB_PATH: another build of the same library, for measurements that compare builds)
+LIB_PATH = os.environ.get("FSA_LIB_PATH") or os.path.join(_HERE, "lib", "libfluidsolver_amd.so")
 
 FSA_OK = 0
 PRECISION_F32, PRECISION_F64 = 0, 1

@@ -36,6 +36,19 @@
 
 namespace fsa {
 
+// Workgroups per CU the register budgets of the two passes are set for.  The density pass runs eight whatever the
+// budget allows (six with 12 more registers to fetch a trip's candidates during the trip before was tried: 1.68 ->
+// 2.06 ms: the pass is bound by instruction issue, LDS instructions included, not by the latency of its LDS reads).
+// The force replay is bound by latency: six workgroups instead of five, 1.43 -> 1.27 ms.
+#ifndef FSA_DENSITY_BLOCKS
+#define FSA_DENSITY_BLOCKS 8
+#endif
+#ifndef FSA_FORCE_BLOCKS
+#define FSA_FORCE_BLOCKS 6
+#endif
+constexpr int kForceBlocks = FSA_FORCE_BLOCKS;
+constexpr int kDensityBlocks = FSA_DENSITY_BLOCKS;
+
 // The wall words of particle i (at `wp`, stride BS), summed in neighbour order.
 template <int BS>
 __device__ __forceinline__ float4 wall_sum(const DevParams<float> &P, int i, const uint2 *__restrict__ wp, int words,
@@ -85,7 +98,7 @@ __device__ __forceinline__ float4 wall_sum(const DevParams<float> &P, int i, con
 // ------------------------------------------------------------------------------------------------
 // EVAL = false: only the record (for a force pass that is not preceded by this solver's density pass).
 template <int BS, int ROWCAP, int Q, bool EVAL>
-__global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> P, int n,
+__global__ __launch_bounds__(BS, kDensityBlocks) void density_record_kernel(DevParams<float> P, int n,
                                                             const float4 *__restrict__ posType,
                                                             const float4 *__restrict__ velMass,
                                                             const float *__restrict__ restDensity,
@@ -256,11 +269,11 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
             // group are kept apart and put in their place afterwards.
             unsigned c0 = 0, c1 = 0, c2 = 0, m = 0, hl = 0;
             int trips = 0;  // the same in every lane
-            auto cull_group = [&](bool go, int g, int lo, int hi, unsigned &bits, auto masked_tag) {
+            auto cull_vals = [&](const float4 &GX, const float4 &GY, const float4 &GZ, int lo, int hi, unsigned &bits,
+                                 auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
-                const int gg = go ? g : Shared::kPad;
                 float d2[kChunk];
-                group_d2<true>(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], pi.x, pi.y, pi.z, d2);
+                group_d2<true>(GX, GY, GZ, pi.x, pi.y, pi.z, d2);
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
                     // (the first and the last group of a range: candidates outside it are moved out of reach)
@@ -281,6 +294,10 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                         bits = bits + bits + hit;
                     }
                 }
+            };
+            auto cull_group = [&](bool go, int g, int lo, int hi, unsigned &bits, auto masked_tag) {
+                const int gg = go ? g : Shared::kPad;
+                cull_vals(sh.x[buf][gg], sh.y[buf][gg], sh.z[buf][gg], lo, hi, bits, masked_tag);
             };
             auto trip_done = [&]() {
                 trips++;
@@ -306,8 +323,8 @@ __global__ __launch_bounds__(BS, 8) void density_record_kernel(DevParams<float> 
                 while ((more = wave_any(base + kChunk <= le))) {
                     const bool go = base + kChunk <= le;
                     cull_group(go, base >> 2, 0, kChunk, m, std::false_type());
-                    trips++;
                     base += go ? kChunk : 0;
+                    trips++;
                     if ((trips & 7) == 0 || (EVAL && wave_any(cnt > Q - kChunk))) break;
                 }
                 if (!more) break;
@@ -464,7 +481,7 @@ template <int ROWCAP> struct PairTile {
 // busy in every trip although a lane's hits per row vary a lot (on a lattice half the lanes have no neighbour at
 // all in a given row).
 template <int BS, int ROWCAP>
-__global__ __launch_bounds__(BS, 5) void force_rows_kernel(DevParams<float> P, int n,
+__global__ __launch_bounds__(BS, kForceBlocks) void force_rows_kernel(DevParams<float> P, int n,
                                                         const float4 *__restrict__ posType,
                                                         const float4 *__restrict__ velMass,
                                                         const float2 *__restrict__ pd,

@@ -8,7 +8,12 @@
 namespace fsa {
 
 constexpr int kTunedBS = 256;
-constexpr int kRowCap = 384;  // typical row: 34 cells x 8 particles = 272
+#ifndef FSA_ROWCAP
+#define FSA_ROWCAP 360
+#endif
+// typical row: 34 cells x 8 particles = 272.  360 entries is what lets SIX workgroups of the WCSPH force replay share a
+// CU's 160 KB of LDS (two tiles of 36-byte entries each; with 384 it was five: 1.43 -> 1.27 ms at 16 M particles)
+constexpr int kRowCap = FSA_ROWCAP;
 // A lattice that lines up with the cell faces puts three particle layers into some cells and one into their
 // neighbours: rows of up to 34 x 2 x 9 = 612 particles.  Blocks with such rows run in a second instantiation
 // of the tiled kernels with larger tiles (fewer blocks per CU, but there are few of them).

@@ -73,7 +73,8 @@ run(a.spinup); g.sync()
 show = a.show if a.show >= 0 else a.world // 2
 for ss in ranks:
     ss.backend.solver.timing_enable(True); ss.backend.solver.timing_reset()
-sent0 = state["sent"]
+state["sent"] = -int(g.sync().records_sent)  # (the group counts from its creation)
+sent0 = 0
 t0 = time.perf_counter()
 run(a.steps, timed=True); st = g.sync()
 wall = time.perf_counter() - t0
