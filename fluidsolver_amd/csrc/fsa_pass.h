@@ -284,8 +284,17 @@ __global__ __launch_bounds__(BS) void tuned_pass_kernel(DevParams<float> P, int 
 // order) and are replayed here, so a pass costs the gathers and the policy's arithmetic only.  Same `pair`
 // calls in the same order as the tiled kernel: same bits.  Blocks the row table marks as not staged, and lanes
 // whose list overflowed, walk the cells.
+// Workgroups per CU the register budgets of the two list kernels are set for (1: whatever the kernel needs).  Forcing
+// more (5 to 8) was measured on the IISPH and DFSPH steps at 16 M particles: the policies with two batches of gathers in
+// flight need their 100-odd registers and spill instead (density-change passes 1.8 -> 5.6 ms per launch).
+#ifndef FSA_LIST_BLOCKS
+#define FSA_LIST_BLOCKS 1
+#endif
+#ifndef FSA_ROWS_BLOCKS
+#define FSA_ROWS_BLOCKS 1
+#endif
 template <typename Policy, int BS, int K>
-__global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n, PassArrays<float> A,
+__global__ __launch_bounds__(BS, FSA_LIST_BLOCKS) void list_pass_kernel(DevParams<float> P, int n, PassArrays<float> A,
                                                        const int *__restrict__ cellStart,
                                                        const int *__restrict__ sortedHash,
                                                        const unsigned short *__restrict__ list,
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(BS) void list_pass_kernel(DevParams<float> P, int n
 // list overflowed take list_pass_kernel's way.
 constexpr int kRowQuorum = 40;
 template <typename Policy, int BS, int ROWCAP, int K>
-__global__ __launch_bounds__(BS) void list_rows_kernel(DevParams<float> P, int n, PassArrays<float> A,
+__global__ __launch_bounds__(BS, FSA_ROWS_BLOCKS) void list_rows_kernel(DevParams<float> P, int n, PassArrays<float> A,
                                                        const int *__restrict__ cellStart,
                                                        const int *__restrict__ sortedHash,
                                                        const unsigned short *__restrict__ list,
