@@ -257,8 +257,8 @@ int fsa_iisph_calc_new_pressure(fsa_solver *s);
 /* IISPHSolvePressure (solver/sph_solver.cu:1409-1443, maxiter = 10 there): rounds until the mean of error[]
  * is below 1e-6 in magnitude or changes by less than 1e-6.  The mean is reduced on the device in double (the
  * reference adds the array up on the host in one float, in index order; since the second test fires when the
- * mean stalls within float rounding, the two can differ in the number of rounds); one read-back per round,
- * so it synchronises.  *rounds = rounds run, *last_mean = last mean; either pointer may be NULL. */
+ * mean stalls within float rounding, the two can differ in the number of rounds).  All rounds are queued at
+ * once and the stop test runs on the device; one read-back at the end of the solve, so it synchronises.  *rounds = rounds run, *last_mean = last mean; either pointer may be NULL. */
 int fsa_iisph_solve_pressure(fsa_solver *s, int maxiter, int *rounds, double *last_mean);
 /* CalcPressureForceKernel alone */
 int fsa_iisph_calc_pressure_force(fsa_solver *s);
