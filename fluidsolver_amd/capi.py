@@ -49,6 +49,11 @@ EXPORTS = (
     "fsa_grid_advect_particles", "fsa_grid_body_force", "fsa_grid_testcase", "fsa_grid_div_velocity",
     "fsa_grid_make_rhs", "fsa_grid_solve", "fsa_grid_update_u", "fsa_grid_mvproduct", "fsa_grid_dotproduct",
     "fsa_grid_step",
+    "fsa_grid_team_create_local", "fsa_grid_team_create_rccl", "fsa_grid_team_destroy", "fsa_grid_team_get_field",
+    "fsa_grid_team_set_field", "fsa_grid_team_set_particles", "fsa_grid_team_get_particles", "fsa_grid_team_advect",
+    "fsa_grid_team_advect_particles", "fsa_grid_team_body_force", "fsa_grid_team_make_rhs",
+    "fsa_grid_team_div_velocity", "fsa_grid_team_solve", "fsa_grid_team_update_u", "fsa_grid_team_step",
+    "fsa_grid_team_sync",
 )
 
 
@@ -199,6 +204,18 @@ def load() -> C.CDLL:
         "fsa_grid_mvproduct": [H, C.c_char_p, C.c_char_p],
         "fsa_grid_dotproduct": [H, C.c_char_p, C.c_char_p, C.POINTER(C.c_double)],
         "fsa_grid_step": [H, C.c_int, C.c_int],
+        "fsa_grid_team_create_local": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                       C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
+        "fsa_grid_team_create_rccl": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
+        "fsa_grid_team_destroy": [H], "fsa_grid_team_get_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
+        "fsa_grid_team_set_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
+        "fsa_grid_team_set_particles": [H, C.c_int, C.c_void_p],
+        "fsa_grid_team_get_particles": [H, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
+        "fsa_grid_team_advect": [H], "fsa_grid_team_advect_particles": [H], "fsa_grid_team_body_force": [H],
+        "fsa_grid_team_make_rhs": [H], "fsa_grid_team_div_velocity": [H, C.POINTER(C.c_double)],
+        "fsa_grid_team_solve": [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)], "fsa_grid_team_update_u": [H],
+        "fsa_grid_team_step": [H, C.c_int, C.c_int], "fsa_grid_team_sync": [H, C.POINTER(C.c_int)],
     }
     for name, args in protos.items():
         f = getattr(lib, name)
@@ -594,6 +611,99 @@ class GridSolver:
     def solve(self, maxiter=-1):
         it, r = C.c_int(), C.c_double()
         check(self.lib.fsa_grid_solve(self._h, int(maxiter), C.byref(it), C.byref(r)))
+        return it.value, r.value
+
+
+class GridTeam:
+    """fsa_grid_team: the grid solver on z-slabs.  Fields go in and out in the single solver's layout (the whole
+    grid).  GridTeam(dim, cuts, ...) holds all slabs in this process; GridTeam.rccl(...) holds slab `rank`."""
+
+    FACE, CELL = GridSolver.FACE, GridSolver.CELL
+
+    def __init__(self, dim, cuts, reach=1, padding=1, h=0.02, dt=0.001, rho=1.0, precision=PRECISION_F32, device: int = 0,
+                 rank=None, uid: bytes = None):
+        self.lib = load()
+        self.precision = precision
+        self.dtype = np.float32 if precision == PRECISION_F32 else np.float64
+        self.dim = tuple(int(d) for d in dim)
+        self.padding = int(padding)
+        self.cuts = [int(c) for c in cuts]
+        world = len(self.cuts) - 1
+        h_ = C.c_void_p()
+        cdim, ccuts = (C.c_int * 3)(*self.dim), (C.c_int * len(self.cuts))(*self.cuts)
+        if rank is None:
+            check(self.lib.fsa_grid_team_create_local(cdim, self.padding, float(h), float(dt), float(rho), precision,
+                                                      device, world, ccuts, int(reach), C.byref(h_)))
+        else:
+            check(self.lib.fsa_grid_team_create_rccl(cdim, self.padding, float(h), float(dt), float(rho), precision,
+                                                     device, int(rank), world, uid, ccuts, int(reach), C.byref(h_)))
+        self._h = h_
+        nx, ny, nz = self.dim
+        pd = self.padding
+        self.shapes = {"u": (nz + 2 * pd, ny + 2 * pd, nx + 2 * pd + 1), "v": (nz + 2 * pd, ny + 2 * pd + 1, nx + 2 * pd),
+                       "w": (nz + 2 * pd + 1, ny + 2 * pd, nx + 2 * pd)}
+
+    @classmethod
+    def rccl(cls, dim, cuts, rank, uid, **kw):
+        return cls(dim, cuts, rank=rank, uid=uid, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fsa_grid_team_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shape(self, name):
+        return self.shapes[name[0]] if name in self.FACE else (self.dim[2], self.dim[1], self.dim[0])
+
+    def get(self, name: str) -> np.ndarray:
+        out = np.zeros(self.shape(name), self.dtype)
+        check(self.lib.fsa_grid_team_get_field(self._h, name.encode(), _ptr(out), out.nbytes))
+        return out
+
+    def set(self, name: str, value) -> None:
+        a = np.ascontiguousarray(value, self.dtype)
+        if a.shape != self.shape(name):
+            raise ValueError(f"field {name}: shape {a.shape}, expected {self.shape(name)}")
+        check(self.lib.fsa_grid_team_set_field(self._h, name.encode(), _ptr(a), a.nbytes))
+
+    def set_particles(self, pos):
+        a = np.ascontiguousarray(pos, self.dtype).reshape(-1, 3)
+        check(self.lib.fsa_grid_team_set_particles(self._h, len(a), _ptr(a)))
+
+    def get_particles(self):
+        n = C.c_int()
+        check(self.lib.fsa_grid_team_get_particles(self._h, None, None, C.byref(n)))
+        pos, col = np.empty((n.value, 3), self.dtype), np.empty((n.value, 4), self.dtype)
+        check(self.lib.fsa_grid_team_get_particles(self._h, _ptr(pos), _ptr(col), C.byref(n)))
+        return pos, col
+
+    def advect(self): check(self.lib.fsa_grid_team_advect(self._h))
+    def advect_particles(self): check(self.lib.fsa_grid_team_advect_particles(self._h))
+    def body_force(self): check(self.lib.fsa_grid_team_body_force(self._h))
+    def make_rhs(self): check(self.lib.fsa_grid_team_make_rhs(self._h))
+    def update_u(self): check(self.lib.fsa_grid_team_update_u(self._h))
+    def step(self, nsteps=1, maxiter=-1): check(self.lib.fsa_grid_team_step(self._h, int(nsteps), int(maxiter)))
+
+    def sync(self) -> int:
+        """waits for the team's work; raises when a back-trace left the planes a slab holds"""
+        bits = C.c_int()
+        check(self.lib.fsa_grid_team_sync(self._h, C.byref(bits)))
+        return bits.value
+
+    def div_velocity(self) -> float:
+        s = C.c_double()
+        check(self.lib.fsa_grid_team_div_velocity(self._h, C.byref(s)))
+        return s.value
+
+    def solve(self, maxiter=-1):
+        it, r = C.c_int(), C.c_double()
+        check(self.lib.fsa_grid_team_solve(self._h, int(maxiter), C.byref(it), C.byref(r)))
         return it.value, r.value
 
 

@@ -13,12 +13,15 @@
 // The CG loop runs without host round trips: its scalars (alpha, beta, the stop decision) live in device
 // memory, every kernel of a round returns at once when the loop has ended, and the host launches rounds in
 // batches and looks at the state between batches.
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "fsa_solver.h"
 
@@ -26,10 +29,18 @@ namespace fsa {
 
 constexpr int kPartials = 2048;  // block partial sums per reduction (grid-stride loops above that)
 
+// A solver works on the z planes [kz0, kz0 + nz) of a grid of gnz planes: all of them (kz0 = 0, gnz = nz, padz = pad),
+// or one z-slab of a team (further down).  nz, zlen, wlen and dimSize describe the planes held; plane indices in the
+// arrays are local (0 = plane kz0), positions and the tests for the faces of the domain use the global index.
+// Face arrays carry padz planes of padding on either side in z: beyond the domain they stay zero, as the
+// reference's padding does; inside it they hold copies of the neighbour slabs' planes.  Cell arrays have one plane
+// before and one after their nz planes for the same purpose.
 template <typename T> struct GridDev {
     int nx, ny, nz, pad;
     int xlen, ylen, zlen, ulen, vlen, wlen;
     int dimSize;
+    int kz0, gnz, padz;
+    int *err;  // slabs only: set when a sample needs a plane the slab does not hold
     T xmin[3];
     T h, dt, rho;
 };
@@ -56,10 +67,14 @@ struct GridSolver {
     double *partials = nullptr;  // 4 * kPartials
     CgState *cg = nullptr;
     double *divsum = nullptr;
+    void *cell_base[6] = {};     // what was allocated for p, divU, b, Aq, r, q (they point one plane in)
     void *ppos = nullptr, *pcolor = nullptr;
     int n_particles = 0, particle_cap = 0;
     int frame = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;      // false: a team's stream
+    // z-slab of a team (kz0 = 0, gnz = nz otherwise)
+    int kz0 = 0, gnz = 0, padz = 0;
     size_t real_size() const { return precision == FSA_PRECISION_F64 ? sizeof(double) : sizeof(float); }
 };
 
@@ -73,13 +88,13 @@ template <typename T> __device__ __forceinline__ int cell_id(const GridDev<T> &G
     return (z * G.ny + y) * G.nx + x;
 }
 template <typename T> __device__ __forceinline__ int u_id(const GridDev<T> &G, int x, int y, int z) {
-    return ((z + G.pad) * G.ylen + y + G.pad) * G.ulen + x + G.pad;
+    return ((z + G.padz) * G.ylen + y + G.pad) * G.ulen + x + G.pad;
 }
 template <typename T> __device__ __forceinline__ int v_id(const GridDev<T> &G, int x, int y, int z) {
-    return ((z + G.pad) * G.vlen + y + G.pad) * G.xlen + x + G.pad;
+    return ((z + G.padz) * G.vlen + y + G.pad) * G.xlen + x + G.pad;
 }
 template <typename T> __device__ __forceinline__ int w_id(const GridDev<T> &G, int x, int y, int z) {
-    return ((z + G.pad) * G.ylen + y + G.pad) * G.xlen + x + G.pad;
+    return ((z + G.padz) * G.ylen + y + G.pad) * G.xlen + x + G.pad;
 }
 
 // ---- sampling (sampleU :301-350, sampleV :352-401, sampleW :403-452) -------------------------------
@@ -90,7 +105,7 @@ constexpr double kSampleEps = 0.000000001;  // the EPSILON in force from :299 on
 template <typename T, int COMP>
 __device__ __forceinline__ T sample_component(const GridDev<T> &G, const T *__restrict__ f, T px, T py, T pz) {
     const T p[3] = {px, py, pz};
-    const int dim[3] = {G.nx, G.ny, G.nz};
+    const int dim[3] = {G.nx, G.ny, G.gnz};
     T x[3];
     int c[3];
 #pragma unroll
@@ -103,7 +118,7 @@ __device__ __forceinline__ T sample_component(const GridDev<T> &G, const T *__re
         if ((double)(x[a] - (T)c[a]) < kSampleEps && x[a] == (T)dim[a]) c[a] -= 1;
         if ((double)x[a] > -kSampleEps && x[a] == (T)-1) c[a] += 1;
     }
-    if (c[0] < 0 || c[0] > G.nx - 1 || c[1] < 0 || c[1] > G.ny - 1 || c[2] < 0 || c[2] > G.nz - 1) return 0;
+    if (c[0] < 0 || c[0] > G.nx - 1 || c[1] < 0 || c[1] > G.ny - 1 || c[2] < 0 || c[2] > G.gnz - 1) return 0;
     T wt[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -114,8 +129,13 @@ __device__ __forceinline__ T sample_component(const GridDev<T> &G, const T *__re
             wt[a] = (T)(((double)p[a] - ((double)G.xmin[a] + ((double)c[a] + 0.5) * (double)G.h)) / (double)G.h);
         }
     }
+    const int zl = c[2] - G.kz0;  // local plane; zl and zl + 1 are read
+    if (G.err && (zl < -G.padz || zl + 1 > G.nz + G.padz - (COMP == 2 ? 0 : 1))) {
+        atomicOr(G.err, 1);
+        return 0;
+    }
     auto at = [&](int dx, int dy, int dz) -> T {
-        const int X = c[0] + dx, Y = c[1] + dy, Z = c[2] + dz;
+        const int X = c[0] + dx, Y = c[1] + dy, Z = zl + dz;
         return f[COMP == 0 ? u_id(G, X, Y, Z) : COMP == 1 ? v_id(G, X, Y, Z) : w_id(G, X, Y, Z)];
     };
     const T w1 = wt[0], w2 = wt[1], w3 = wt[2];
@@ -141,7 +161,8 @@ template <typename T, int COMP>
 __global__ __launch_bounds__(kBlock) void grid_advect_kernel(GridDev<T> G, const T *__restrict__ u,
                                                              const T *__restrict__ v, const T *__restrict__ w,
                                                              T *__restrict__ out) {
-    const int ex = G.nx + (COMP == 0), ey = G.ny + (COMP == 1), ez = G.nz + (COMP == 2);
+    // (the face on top of the last plane belongs to the slab that ends the domain)
+    const int ex = G.nx + (COMP == 0), ey = G.ny + (COMP == 1), ez = G.nz + (COMP == 2 && G.kz0 + G.nz == G.gnz);
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (long long)ex * ey * ez) return;
     const int i = (int)(t % ex), j = (int)((t / ex) % ey), k = (int)(t / ((long long)ex * ey));
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void grid_advect_kernel(GridDev<T> G, const
         vel[2] = 0;
         xt[0] = at_face(G, 0, i);
         xt[1] = at_centre(G, 1, j);
-        xt[2] = at_centre(G, 2, k);
+        xt[2] = at_centre(G, 2, k + G.kz0);
         const T s = (T)-1;
         out[u_id(G, i, j, k)] = sample_component<T, 0>(G, u, xt[0] + vel[0] * G.dt * s, xt[1] + vel[1] * G.dt * s,
                                                        xt[2] + vel[2] * G.dt * s);
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void grid_advect_kernel(GridDev<T> G, const
                          w[w_id(G, i, j - 1, k + 1)]);
         xt[0] = at_centre(G, 0, i);
         xt[1] = at_face(G, 1, j);
-        xt[2] = at_centre(G, 2, k);
+        xt[2] = at_centre(G, 2, k + G.kz0);
     } else {
         vel[0] = quarter(u[u_id(G, i, j, k)], u[u_id(G, i, j, k - 1)], u[u_id(G, i + 1, j, k)],
                          u[u_id(G, i + 1, j, k - 1)]);
@@ -175,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void grid_advect_kernel(GridDev<T> G, const
         vel[2] = w[w_id(G, i, j, k)];
         xt[0] = at_centre(G, 0, i);
         xt[1] = at_centre(G, 1, j);
-        xt[2] = at_face(G, 2, k);
+        xt[2] = at_face(G, 2, k + G.kz0);
     }
     const T half = (T)-0.5, full = (T)-1;
     const T mx = xt[0] + vel[0] * G.dt * half, my = xt[1] + vel[1] * G.dt * half, mz = xt[2] + vel[2] * G.dt * half;
@@ -190,14 +211,22 @@ __global__ __launch_bounds__(kBlock) void grid_advect_kernel(GridDev<T> G, const
 }
 
 // advectParticles :639-651
+// A slab moves the tracers that lie in its own planes (those below or above the domain go with the first and the
+// last slab) and writes them to a second pair of arrays: another slab must not move a tracer again that has just
+// arrived in its planes.  The single solver works in place (src == pos).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void grid_advect_particles_kernel(GridDev<T> G, int n, const T *__restrict__ u,
                                                                        const T *__restrict__ v,
-                                                                       const T *__restrict__ w, T *__restrict__ pos,
-                                                                       T *__restrict__ color) {
+                                                                       const T *__restrict__ w, const T *src, T *pos,
+                                                                       T *color) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    T x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+    T x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1], z = src[3 * (size_t)i + 2];
+    if (G.err) {
+        int c = (int)g_floor((z - G.xmin[2]) / G.h);
+        c = c < 0 ? 0 : c > G.gnz - 1 ? G.gnz - 1 : c;
+        if (!(c >= G.kz0 && c < G.kz0 + G.nz)) return;  // (a position that is not a number goes nowhere)
+    }
     const T vx = sample_component<T, 0>(G, u, x, y, z);
     const T vy = sample_component<T, 1>(G, v, x, y, z);
     const T vz = sample_component<T, 2>(G, w, x, y, z);
@@ -211,12 +240,13 @@ __global__ __launch_bounds__(kBlock) void grid_advect_particles_kernel(GridDev<T
 }
 
 // bodyForce :579-588
+// (planes [k0, k0 + nk): a slab does its copies of the neighbours' planes as well, with the same operation)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void grid_body_force_kernel(GridDev<T> G, T *__restrict__ v) {
+__global__ __launch_bounds__(kBlock) void grid_body_force_kernel(GridDev<T> G, T *__restrict__ v, int k0, int nk) {
     const int ey = G.ny + 1;
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (long long)G.nx * ey * G.nz) return;
-    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % ey), k = (int)(t / ((long long)G.nx * ey));
+    if (t >= (long long)G.nx * ey * nk) return;
+    const int i = (int)(t % G.nx), j = (int)((t / G.nx) % ey), k = k0 + (int)(t / ((long long)G.nx * ey));
     v[v_id(G, i, j, k)] += 10 * G.dt;
 }
 
@@ -371,8 +401,8 @@ __device__ __forceinline__ T laplace_cell(const GridDev<T> &G, const T *__restri
     if (i == G.nx - 1) res += c; else res += c - x[t + 1];
     if (j == 0) res += 0; else res += c - x[t - sy];
     if (j == G.ny - 1) res += c; else res += c - x[t + sy];
-    if (k == 0) res += c; else res += c - x[t - sz];
-    if (k == G.nz - 1) res += c; else res += c - x[t + sz];
+    if (k + G.kz0 == 0) res += c; else res += c - x[t - sz];
+    if (k + G.kz0 == G.gnz - 1) res += c; else res += c - x[t + sz];
     return res;
 }
 
@@ -395,8 +425,8 @@ __device__ __forceinline__ Quad<T> laplace_quad_terms(const GridDev<T> &G, int i
         if (i0 + e == G.nx - 1) res += cc; else res += cc - right;
         if (j == 0) res += 0; else res += cc - ym.v[e];
         if (j == G.ny - 1) res += cc; else res += cc - yp.v[e];
-        if (k == 0) res += cc; else res += cc - zm.v[e];
-        if (k == G.nz - 1) res += cc; else res += cc - zp.v[e];
+        if (k + G.kz0 == 0) res += cc; else res += cc - zm.v[e];
+        if (k + G.kz0 == G.gnz - 1) res += cc; else res += cc - zp.v[e];
         out.v[e] = res;
     }
     return out;
@@ -411,8 +441,8 @@ __device__ __forceinline__ Quad<T> laplace_quad(const GridDev<T> &G, const T *__
     const Quad<T> c = *reinterpret_cast<const Quad<T> *>(x + t);
     const Quad<T> ym = j > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sy) : zero;
     const Quad<T> yp = j < G.ny - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sy) : zero;
-    const Quad<T> zm = k > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sz) : zero;
-    const Quad<T> zp = k < G.nz - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sz) : zero;
+    const Quad<T> zm = k + G.kz0 > 0 ? *reinterpret_cast<const Quad<T> *>(x + t - sz) : zero;
+    const Quad<T> zp = k + G.kz0 < G.gnz - 1 ? *reinterpret_cast<const Quad<T> *>(x + t + sz) : zero;
     const T xm = i0 > 0 ? x[t - 1] : (T)0, xp = i0 + 4 < G.nx ? x[t + 4] : (T)0;
     centre = c;
     return laplace_quad_terms(G, i0, j, k, c, xm, xp, ym, yp, zm, zp);
@@ -542,11 +572,11 @@ __global__ __launch_bounds__(kBlock) void cg_matvec_march_kernel(GridDev<T> G, c
     if (kbeg < kend) {  // the same for the whole block
         const size_t rowq = (size_t)qx, planeq = rowq * (size_t)G.ny;
         size_t Q = (size_t)kbeg * planeq + (size_t)(active ? j : 0) * rowq + (size_t)qc;
-        Quad<T> zm = (active && kbeg > 0) ? q4[Q - planeq] : zero;
+        Quad<T> zm = (active && kbeg + G.kz0 > 0) ? q4[Q - planeq] : zero;
         Quad<T> c = active ? q4[Q] : zero;
         for (int k = kbeg; k < kend; k++, Q += planeq) {
             const int buf = (k - kbeg) & 1;
-            const Quad<T> zp = (active && k + 1 < G.nz) ? q4[Q + planeq] : zero;
+            const Quad<T> zp = (active && k + 1 + G.kz0 < G.gnz) ? q4[Q + planeq] : zero;
             const Quad<T> rv = active ? r4[Q] : zero;
             Quad<T> ym = zero, yp = zero;
             if (active && first_row && j > 0) ym = q4[Q - rowq];
@@ -574,12 +604,7 @@ __global__ __launch_bounds__(kBlock) void cg_matvec_march_kernel(GridDev<T> G, c
 }
 
 // :183-188: the "trivial all-zero" break and alpha = rr / qAq, in the solver's precision
-template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_alpha_kernel(CgState *cg, const double *__restrict__ partials, int nb) {
-    if (cg_over(cg)) return;
-    const double rr = sum_partials(partials, 0, nb);
-    const double qAq = sum_partials(partials, 1, nb);
-    if (threadIdx.x != 0) return;
+template <typename T> __device__ __forceinline__ void cg_alpha_apply(CgState *cg, double rr, double qAq) {
     const T rrT = (T)rr, qAqT = (T)qAq;
     cg->rr = (double)rrT;
     cg->qAq = (double)qAqT;
@@ -588,6 +613,15 @@ __global__ __launch_bounds__(kBlock) void cg_alpha_kernel(CgState *cg, const dou
         return;
     }
     cg->alpha = (double)(T)(rrT / qAqT);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_alpha_kernel(CgState *cg, const double *__restrict__ partials, int nb) {
+    if (cg_over(cg)) return;
+    const double rr = sum_partials(partials, 0, nb);
+    const double qAq = sum_partials(partials, 1, nb);
+    if (threadIdx.x != 0) return;
+    cg_alpha_apply<T>(cg, rr, qAq);
 }
 
 // :190-193 and the sums behind :195 and :201: p += alpha q; r -= alpha Aq; partial r.r and |r|
@@ -611,12 +645,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(GridDev<T> G, const C
 }
 
 // :195, :203-207: beta, the mean residual, the stop test, iter++ (and this build's optional cap)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_beta_kernel(CgState *cg, const double *__restrict__ partials, int nb, int n) {
-    if (cg_over(cg)) return;
-    const double rr_new = sum_partials(partials + 2 * kPartials, 0, nb);
-    const double rabs_sum = sum_partials(partials + 2 * kPartials, 1, nb);
-    if (threadIdx.x != 0) return;
+template <typename T> __device__ __forceinline__ void cg_beta_apply(CgState *cg, double rr_new, double rabs_sum, int n) {
     const T rrT = (T)cg->rr;
     cg->rr_new = (double)(T)rr_new;
     cg->beta = (double)(T)((T)rr_new / rrT);
@@ -634,6 +663,55 @@ __global__ __launch_bounds__(kBlock) void cg_beta_kernel(CgState *cg, const doub
     }
     cg->iter++;
     if (cg->maxiter >= 0 && cg->iter >= cg->maxiter) cg->pending = 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_beta_kernel(CgState *cg, const double *__restrict__ partials, int nb, int n) {
+    if (cg_over(cg)) return;
+    const double rr_new = sum_partials(partials + 2 * kPartials, 0, nb);
+    const double rabs_sum = sum_partials(partials + 2 * kPartials, 1, nb);
+    if (threadIdx.x != 0) return;
+    cg_beta_apply<T>(cg, rr_new, rabs_sum, n);
+}
+
+// ---- the sums of a team of z-slabs --------------------------------------------------------------------------
+// Every slab's kernels leave block partials in the slab's own array; one block adds them up, slab after slab in
+// the order of the planes, and the same total goes to every slab's loop state, which therefore takes the same
+// decisions as its neighbours'.  Between processes the per-process totals are added by an all-reduce between the
+// two kernels.
+constexpr int kMaxTeam = 16;
+struct TeamParts {
+    const double *partials[kMaxTeam];
+    CgState *cg[kMaxTeam];
+    int nb[kMaxTeam];
+    int count;
+};
+
+// out[0], out[1] = totals of the partial-sum slots 0 and (if `two`) 1 at `offset` in every slab's array
+__global__ __launch_bounds__(kBlock) void team_sum_kernel(TeamParts tp, int offset, int two, double *__restrict__ out) {
+    double a = 0.0, b = 0.0;
+    for (int m = 0; m < tp.count; m++) {
+        const double sa = sum_partials(tp.partials[m] + offset, 0, tp.nb[m]);
+        const double sb = two ? sum_partials(tp.partials[m] + offset, 1, tp.nb[m]) : 0.0;
+        a = m == 0 ? sa : a + sa;
+        b = m == 0 ? sb : b + sb;
+    }
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        out[1] = b;
+    }
+}
+
+template <typename T> __global__ void team_alpha_kernel(TeamParts tp, const double *__restrict__ sums) {
+    const int m = threadIdx.x;
+    if (m >= tp.count || cg_over(tp.cg[m])) return;
+    cg_alpha_apply<T>(tp.cg[m], sums[0], sums[1]);
+}
+
+template <typename T> __global__ void team_beta_kernel(TeamParts tp, const double *__restrict__ sums, int n) {
+    const int m = threadIdx.x;
+    if (m >= tp.count || cg_over(tp.cg[m])) return;
+    cg_beta_apply<T>(tp.cg[m], sums[0], sums[1], n);
 }
 
 // :199-200: q = r + beta q, for round number `round` (0-based, counted by the host as it launches): runs
@@ -655,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void grid_update_u_kernel(GridDev<T> G, con
                                                                T *__restrict__ v, T *__restrict__ w) {
     const T c = G.dt / G.rho / G.h;
     const long long nu = (long long)(G.nx + 1) * G.ny * G.nz, nv = (long long)G.nx * (G.ny + 1) * G.nz,
-                    nw = (long long)G.nx * G.ny * (G.nz + 1);
+                    nw = (long long)G.nx * G.ny * (G.nz + (G.kz0 + G.nz == G.gnz));
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t < nu) {
         const int ex = G.nx + 1;
@@ -680,8 +758,8 @@ __global__ __launch_bounds__(kBlock) void grid_update_u_kernel(GridDev<T> G, con
     if (t < nw) {
         const int i = (int)(t % G.nx), j = (int)((t / G.nx) % G.ny), k = (int)(t / ((long long)G.nx * G.ny));
         T *f = &w[w_id(G, i, j, k)];
-        if (k == 0) *f -= (p[cell_id(G, i, j, 0)] - 0) * c;
-        else if (k < G.nz) *f -= (p[cell_id(G, i, j, k)] - p[cell_id(G, i, j, k - 1)]) * c;
+        if (k + G.kz0 == 0) *f -= (p[cell_id(G, i, j, 0)] - 0) * c;
+        else if (k + G.kz0 < G.gnz) *f -= (p[cell_id(G, i, j, k)] - p[cell_id(G, i, j, k - 1)]) * c;
         else *f -= (0 - p[cell_id(G, i, j, G.nz - 1)]) * c;
     }
 }
@@ -694,18 +772,19 @@ static inline int rblocks(long long n) {
     return (int)((want + kXcdCount - 1) / kXcdCount * kXcdCount);
 }
 
-template <typename T> static void fill_dev(const GridSolver *g, GridDev<T> &G, const int dim[3], int pad, double h,
-                                           double dt, double rho) {
-    G.nx = dim[0]; G.ny = dim[1]; G.nz = dim[2]; G.pad = pad;
-    G.xlen = dim[0] + 2 * pad; G.ylen = dim[1] + 2 * pad; G.zlen = dim[2] + 2 * pad;
+// `dim` is the whole grid; the solver holds its planes [kz0, kz0 + nz) with padz planes of padding in z
+template <typename T> static void fill_dev(GridDev<T> &G, const int dim[3], int pad, double h, double dt, double rho,
+                                           int kz0, int nz, int padz, int *err) {
+    G.nx = dim[0]; G.ny = dim[1]; G.nz = nz; G.pad = pad;
+    G.kz0 = kz0; G.gnz = dim[2]; G.padz = padz; G.err = err;
+    G.xlen = dim[0] + 2 * pad; G.ylen = dim[1] + 2 * pad; G.zlen = nz + 2 * padz;
     G.ulen = G.xlen + 1; G.vlen = G.ylen + 1; G.wlen = G.zlen + 1;
-    G.dimSize = dim[0] * dim[1] * dim[2];
+    G.dimSize = dim[0] * dim[1] * nz;
     G.h = (T)h; G.dt = (T)dt; G.rho = (T)rho;
     // loadConfig :26-28: `-grid.dim.x/2*grid.h` negates, divides as integers, then multiplies
     G.xmin[0] = (T)(-dim[0] / 2) * G.h;
     G.xmin[1] = 0;
     G.xmin[2] = (T)(-dim[2] / 2) * G.h;
-    (void)g;
 }
 
 #define GRID_LAUNCH(kernel, grid, ...)                                                                      \
@@ -725,11 +804,11 @@ template <typename T> static void fill_dev(const GridSolver *g, GridDev<T> &G, c
     } while (0)
 
 static void grid_free(GridSolver *g) {
-    void *ptrs[] = {g->u, g->v, g->w, g->uadv, g->vadv, g->wadv, g->p, g->divU, g->b, g->Aq, g->r, g->q,
-                    g->partials, g->cg, g->divsum, g->ppos, g->pcolor};
+    void *ptrs[] = {g->u, g->v, g->w, g->uadv, g->vadv, g->wadv, g->cell_base[0], g->cell_base[1], g->cell_base[2],
+                    g->cell_base[3], g->cell_base[4], g->cell_base[5], g->partials, g->cg, g->divsum, g->ppos, g->pcolor};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->stream && g->own_stream) (void)hipStreamDestroy(g->stream);
 }
 
 static int galloc(void **out, size_t bytes) {
@@ -747,7 +826,7 @@ static int grid_advect(GridSolver *g) {
                 (const T *)g->w, (T *)g->uadv);
     GRID_LAUNCH((grid_advect_kernel<T, 1>), gblocks(nx * (ny + 1) * nz), G, (const T *)g->u, (const T *)g->v,
                 (const T *)g->w, (T *)g->vadv);
-    GRID_LAUNCH((grid_advect_kernel<T, 2>), gblocks(nx * ny * (nz + 1)), G, (const T *)g->u, (const T *)g->v,
+    GRID_LAUNCH((grid_advect_kernel<T, 2>), gblocks(nx * ny * (nz + (g->kz0 + nz == g->gnz))), G, (const T *)g->u, (const T *)g->v,
                 (const T *)g->w, (T *)g->wadv);
     std::swap(g->u, g->uadv);  // swapBuffer :573-577
     std::swap(g->v, g->vadv);
@@ -758,12 +837,15 @@ static int grid_advect(GridSolver *g) {
 static int grid_advect_particles(GridSolver *g) {
     if (g->n_particles == 0) return FSA_OK;
     GRID_LAUNCH(grid_advect_particles_kernel<T>, gblocks(g->n_particles), G, g->n_particles, (const T *)g->u,
-                (const T *)g->v, (const T *)g->w, (T *)g->ppos, (T *)g->pcolor);
+                (const T *)g->v, (const T *)g->w, (const T *)g->ppos, (T *)g->ppos, (T *)g->pcolor);
     return FSA_OK;
 }
 
 static int grid_body_force(GridSolver *g) {
-    GRID_LAUNCH(grid_body_force_kernel<T>, gblocks((long long)g->gf.nx * (g->gf.ny + 1) * g->gf.nz), G, (T *)g->v);
+    // a slab: its copies of the neighbours' planes too (not the padding beyond the domain, which stays zero)
+    const int below = g->kz0 > 0 ? g->padz : 0, above = g->kz0 + g->gf.nz < g->gnz ? g->padz : 0;
+    const int nk = below + g->gf.nz + above;
+    GRID_LAUNCH(grid_body_force_kernel<T>, gblocks((long long)g->gf.nx * (g->gf.ny + 1) * nk), G, (T *)g->v, -below, nk);
     return FSA_OK;
 }
 
@@ -782,54 +864,84 @@ static int grid_div(GridSolver *g, bool with_rhs) {
 
 static int grid_update_u(GridSolver *g) {
     const long long nx = g->gf.nx, ny = g->gf.ny, nz = g->gf.nz;
-    const long long faces = (nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + 1);
+    const long long faces = (nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + (g->kz0 + nz == g->gnz));
     GRID_LAUNCH(grid_update_u_kernel<T>, gblocks(faces), G, (const T *)g->p, (T *)g->u, (T *)g->v, (T *)g->w);
     return FSA_OK;
 }
 
 constexpr int kCgBatch = 16;  // rounds launched between two looks at the loop state
 
-static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, int *rounds) {
-    const int nb = rblocks(g->dimSize);
-    hipLaunchKernelGGL(cg_reset_kernel, dim3(1), dim3(1), 0, g->stream, g->cg, maxiter);
-    const bool quad = g->gf.nx % 4 == 0;
-    const int nbq = quad ? rblocks(g->dimSize / 4) : nb;  // blocks of the stencil kernels
+// which stencil kernel a solver's planes take, and with how many blocks
+struct SolvePlan {
+    bool quad = false, march = false;
+    int nb = 0, nbq = 0, tiles = 0, zsegs = 0, nbm = 0, nb_dots = 0;
+};
+static SolvePlan solve_plan(const GridSolver *g) {
+    SolvePlan pl;
+    pl.nb = rblocks(g->dimSize);
+    pl.quad = g->gf.nx % 4 == 0;
+    pl.nbq = pl.quad ? rblocks(g->dimSize / 4) : pl.nb;  // blocks of the stencil kernels
     // the z-marching stencil: rows of a power-of-two number of four-cell groups, and few enough tiles
     const int qx = g->gf.nx / 4;
-    bool march = quad && qx <= kBlock && (qx & (qx - 1)) == 0 && !std::getenv("FSA_GRID_NO_MARCH");
-    int tiles = 0, zsegs = 0, nbm = 0;
-    if (march) {
+    pl.march = pl.quad && qx <= kBlock && (qx & (qx - 1)) == 0 && !std::getenv("FSA_GRID_NO_MARCH");
+    if (pl.march) {
         const int rows = kBlock / qx, slab = (g->gf.nz + (int)kXcdCount - 1) / (int)kXcdCount;
-        tiles = (g->gf.ny + rows - 1) / rows;
-        zsegs = std::max(1, std::min(slab, (kPartials / (int)kXcdCount) / std::max(tiles, 1)));
-        nbm = (int)kXcdCount * tiles * zsegs;
-        if (tiles > kPartials / (int)kXcdCount) march = false;
+        pl.tiles = (g->gf.ny + rows - 1) / rows;
+        pl.zsegs = std::max(1, std::min(slab, (kPartials / (int)kXcdCount) / std::max(pl.tiles, 1)));
+        pl.nbm = (int)kXcdCount * pl.tiles * pl.zsegs;
+        if (pl.tiles > kPartials / (int)kXcdCount) pl.march = false;
     }
-    const int nb_dots = march ? nbm : nbq;
-    if (quad)
-        GRID_LAUNCH((cg_init_kernel<T, true>), nbq, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
+    pl.nb_dots = pl.march ? pl.nbm : pl.nbq;
+    return pl;
+}
+
+static int launch_cg_init(GridSolver *g, const SolvePlan &pl) {
+    if (pl.quad)
+        GRID_LAUNCH((cg_init_kernel<T, true>), pl.nbq, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
                     (T *)g->q);
     else
-        GRID_LAUNCH((cg_init_kernel<T, false>), nb, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
+        GRID_LAUNCH((cg_init_kernel<T, false>), pl.nb, G, (const T *)g->p, (const T *)g->b, (T *)g->Aq, (T *)g->r,
                     (T *)g->q);
+    return FSA_OK;
+}
+
+static int launch_cg_matvec(GridSolver *g, const SolvePlan &pl) {
+    if (pl.march)
+        GRID_LAUNCH(cg_matvec_march_kernel<T>, pl.nbm, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
+                    g->partials, pl.tiles, pl.zsegs);
+    else if (pl.quad)
+        GRID_LAUNCH((cg_matvec_kernel<T, true>), pl.nbq, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
+                    g->partials);
+    else
+        GRID_LAUNCH((cg_matvec_kernel<T, false>), pl.nb, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
+                    g->partials);
+    return FSA_OK;
+}
+
+static int launch_mvproduct_p(GridSolver *g, const SolvePlan &pl) {  // :210
+    if (pl.quad)
+        GRID_LAUNCH((grid_mvproduct_kernel<T, true>), pl.nbq, G, (const T *)g->p, (T *)g->Aq);
+    else
+        GRID_LAUNCH((grid_mvproduct_kernel<T, false>), pl.nb, G, (const T *)g->p, (T *)g->Aq);
+    return FSA_OK;
+}
+
+static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, int *rounds) {
+    const SolvePlan pl = solve_plan(g);
+    hipLaunchKernelGGL(cg_reset_kernel, dim3(1), dim3(1), 0, g->stream, g->cg, maxiter);
+    int rc = launch_cg_init(g, pl);
+    if (rc) return rc;
     CgState st{};
     int round = 0;
     for (;;) {
         for (int k = 0; k < kCgBatch; k++, round++) {
-            if (march)
-                GRID_LAUNCH(cg_matvec_march_kernel<T>, nbm, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
-                            g->partials, tiles, zsegs);
-            else if (quad)
-                GRID_LAUNCH((cg_matvec_kernel<T, true>), nbq, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
-                            g->partials);
-            else
-                GRID_LAUNCH((cg_matvec_kernel<T, false>), nb, G, g->cg, (const T *)g->q, (const T *)g->r, (T *)g->Aq,
-                            g->partials);
-            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, nb_dots);
-            GRID_LAUNCH(cg_update_kernel<T>, nb, G, g->cg, (const T *)g->q, (const T *)g->Aq, (T *)g->p, (T *)g->r,
+            rc = launch_cg_matvec(g, pl);
+            if (rc) return rc;
+            GRID_LAUNCH(cg_alpha_kernel<T>, 1, g->cg, g->partials, pl.nb_dots);
+            GRID_LAUNCH(cg_update_kernel<T>, pl.nb, G, g->cg, (const T *)g->q, (const T *)g->Aq, (T *)g->p, (T *)g->r,
                         g->partials);
-            GRID_LAUNCH(cg_beta_kernel<T>, 1, g->cg, g->partials, nb, g->dimSize);
-            GRID_LAUNCH(cg_direction_kernel<T>, nb, G, g->cg, round, (const T *)g->r, (T *)g->q);
+            GRID_LAUNCH(cg_beta_kernel<T>, 1, g->cg, g->partials, pl.nb, g->dimSize);
+            GRID_LAUNCH(cg_direction_kernel<T>, pl.nb, G, g->cg, round, (const T *)g->r, (T *)g->q);
         }
         FSA_HIP(hipMemcpyAsync(&st, g->cg, sizeof(st), hipMemcpyDeviceToHost, g->stream));
         FSA_HIP(counted_stream_sync(g->stream));
@@ -837,14 +949,76 @@ static int grid_solve(GridSolver *g, int maxiter, int *iters, double *residual, 
     }
     if (st.finished == 2)
         return fail(FSA_ERR_INVALID, "conjugate gradients: the residual is not a number after %d rounds", st.rounds);
-    // :210
-    if (quad)
-        GRID_LAUNCH((grid_mvproduct_kernel<T, true>), nbq, G, (const T *)g->p, (T *)g->Aq);
-    else
-        GRID_LAUNCH((grid_mvproduct_kernel<T, false>), nb, G, (const T *)g->p, (T *)g->Aq);
+    rc = launch_mvproduct_p(g, pl);
+    if (rc) return rc;
     if (iters) *iters = st.iter;
     if (residual) *residual = st.rabs;
     if (rounds) *rounds = st.rounds;
+    return FSA_OK;
+}
+
+static int grid_check_args(const int dim[3], int padding, double h, double dt, double rho, int precision, int device) {
+    if (!dim || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0) return fail(FSA_ERR_INVALID, "dim must be positive");
+    // the advection reads one face outside the effective grid on every side
+    if (padding < 1) return fail(FSA_ERR_INVALID, "padding %d: at least 1 is needed", padding);
+    if (!(h > 0) || !(dt > 0) || !(rho > 0)) return fail(FSA_ERR_INVALID, "h, dt and rho must be positive");
+    if (precision != FSA_PRECISION_F32 && precision != FSA_PRECISION_F64)
+        return fail(FSA_ERR_INVALID, "unknown precision %d", precision);
+    const double faces = ((double)dim[0] + 2 * padding + 1) * ((double)dim[1] + 2 * padding + 1) *
+                         ((double)dim[2] + 2 * padding + 1);
+    if (faces >= 2147483647.0) return fail(FSA_ERR_INVALID, "grid too large for 32-bit face indices");
+    int ndev = 0;
+    FSA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(FSA_ERR_INVALID, "device %d of %d", device, ndev);
+    return FSA_OK;
+}
+
+// A solver for the planes [kz0, kz0 + nz) of the grid `dim` (all of them: kz0 = 0, nz = dim[2], padz = padding).
+// `stream` != nullptr: work goes there (a team's stream) instead of a stream of the solver's own.
+static int grid_make(const int dim[3], int padding, double h, double dt, double rho, int precision, int device, int kz0,
+                     int nz, int padz, int *err, hipStream_t stream, GridSolver **out) {
+    GridSolver *g = new (std::nothrow) GridSolver();
+    if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
+    g->precision = precision;
+    g->device = device;
+    g->kz0 = kz0;
+    g->gnz = dim[2];
+    g->padz = padz;
+    fill_dev(g->gf, dim, padding, h, dt, rho, kz0, nz, padz, err);
+    fill_dev(g->gd, dim, padding, h, dt, rho, kz0, nz, padz, err);
+    g->uSize = g->gf.ulen * g->gf.ylen * g->gf.zlen;
+    g->vSize = g->gf.xlen * g->gf.vlen * g->gf.zlen;
+    g->wSize = g->gf.xlen * g->gf.ylen * g->gf.wlen;
+    g->dimSize = g->gf.dimSize;
+    int rc = FSA_OK;
+    if (hipSetDevice(device) != hipSuccess) rc = fail(FSA_ERR_HIP, "hipSetDevice failed");
+    if (stream) {
+        g->stream = stream;
+        g->own_stream = false;
+    } else if (rc == FSA_OK && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
+        rc = fail(FSA_ERR_HIP, "hipStreamCreate failed");
+    }
+    const size_t R = g->real_size();
+    void **face[] = {&g->u, &g->v, &g->w, &g->uadv, &g->vadv, &g->wadv};
+    const size_t face_n[] = {(size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize,
+                             (size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize};
+    for (int k = 0; k < 6 && rc == FSA_OK; k++) rc = galloc(face[k], face_n[k] * R);
+    // cell arrays: one plane before and one after (zero; a slab's copies of its neighbours' planes go there)
+    void **cell[] = {&g->p, &g->divU, &g->b, &g->Aq, &g->r, &g->q};
+    const size_t plane = (size_t)dim[0] * dim[1];
+    for (int k = 0; k < 6 && rc == FSA_OK; k++) {
+        rc = galloc(&g->cell_base[k], ((size_t)g->dimSize + 2 * plane) * R);
+        if (rc == FSA_OK) *cell[k] = (char *)g->cell_base[k] + plane * R;
+    }
+    if (rc == FSA_OK) rc = galloc((void **)&g->partials, 4 * kPartials * sizeof(double));
+    if (rc == FSA_OK) rc = galloc((void **)&g->cg, sizeof(CgState));
+    if (rc == FSA_OK) rc = galloc((void **)&g->divsum, 2 * sizeof(double));
+    if (rc != FSA_OK) {
+        grid_free(g);
+        delete g;
+        return rc;
+    }
+    *out = g;
     return FSA_OK;
 }
 
@@ -863,6 +1037,396 @@ static void *grid_field(GridSolver *g, const std::string &k, size_t *count) {
     if (k == "r") { *count = C; return g->r; }
     if (k == "q") { *count = C; return g->q; }
     return nullptr;
+}
+
+
+// ---- a team of z-slabs ----------------------------------------------------------------------------------
+// The grid cut into slabs of whole z planes, one solver each (GridDev::kz0 ..).  The reference has one grid on one
+// host (solver/grid_solver.cpp); what the cut adds is
+//   * copies of the neighbours' planes: `padz` planes of the face arrays (the back-trace of the advection may leave
+//     a slab by padz - 1 planes; a sample that needs more raises the team's error word), refreshed after the
+//     advection and after the velocity update; one plane of p before the first and after the last stencil of a
+//     solve, one plane of q before every stencil in between;
+//   * sums over all slabs for the two dot products and the residual of every round and for the divergence sum.
+// LOCAL teams hold all slabs in this process on one GPU and one stream (a rehearsal, and the reference for the
+// other kind): refreshes are device copies.  RCCL teams hold one slab per process: refreshes are ncclSend /
+// ncclRecv pairs with the z-neighbours, the sums an ncclAllReduce of two doubles, all queued on the stream; the
+// loop state is the same on every rank, so every rank queues the same rounds.
+struct GridTeam {
+    int kind = 0;  // 0 LOCAL, 1 RCCL
+    int world = 1, rank = 0;
+    int dim[3] = {0, 0, 0}, pad = 1, padz = 2, precision = FSA_PRECISION_F32, device = 0;
+    std::vector<int> cuts;
+    std::vector<GridSolver *> m;  // this process's slabs, bottom to top
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    int *err = nullptr;      // device
+    double *sums = nullptr;  // device, two doubles
+    void *ppos = nullptr, *pcolor = nullptr, *pnew = nullptr, *pcnew = nullptr;
+    int n_particles = 0, particle_cap = 0;
+    int frame = 0;
+    size_t real_size() const { return precision == FSA_PRECISION_F64 ? sizeof(double) : sizeof(float); }
+    bool first_slab(const GridSolver *g) const { return g->kz0 == 0; }
+    bool last_slab(const GridSolver *g) const { return g->kz0 + g->gf.nz == g->gnz; }
+};
+
+static void team_free(GridTeam *t) {
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    for (GridSolver *g : t->m) {
+        grid_free(g);
+        delete g;
+    }
+    if (t->comm) (void)ncclCommDestroy(t->comm);
+    void *ptrs[] = {t->err, t->sums, t->ppos, t->pcolor, t->pnew, t->pcnew};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+}
+
+enum { kFaceU = 0, kFaceV = 1, kFaceW = 2 };
+static void *face_ptr(GridSolver *g, int f) { return f == kFaceU ? g->u : f == kFaceV ? g->v : g->w; }
+static size_t face_plane(const GridSolver *g, int f) {
+    const GridDev<float> &G = g->gf;
+    return f == kFaceU ? (size_t)G.ylen * G.ulen : f == kFaceV ? (size_t)G.vlen * G.xlen : (size_t)G.ylen * G.xlen;
+}
+enum { kCellP = 0, kCellDiv, kCellB, kCellAq, kCellR, kCellQ };
+static void *cell_ptr(GridSolver *g, int c) {
+    void *v[] = {g->p, g->divU, g->b, g->Aq, g->r, g->q};
+    return v[c];
+}
+
+#define TEAM_NCCL(expr)                                                                                \
+    do {                                                                                               \
+        ncclResult_t _r = (expr);                                                                      \
+        if (_r != ncclSuccess) return fail(FSA_ERR_HIP, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
+    } while (0)
+
+// One run of bytes to the slab below / above and one from it: [0] = with the slab below, [1] = with the slab above.
+struct HaloRuns {
+    char *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};
+    size_t send_bytes[2] = {0, 0}, recv_bytes[2] = {0, 0};
+};
+
+// what slab g exchanges for face array f (padz planes up, padz (+ 1 for w: the shared face belongs to the upper
+// slab) planes down) or, planes == 0, for cell array f (one plane each way)
+static HaloRuns halo_runs(const GridTeam *t, GridSolver *g, bool faces, int f) {
+    HaloRuns h;
+    const size_t R = t->real_size();
+    const int nz = g->gf.nz;
+    if (faces) {
+        const size_t st = face_plane(g, f) * R;
+        char *base = (char *)face_ptr(g, f);
+        const int pz = t->padz, extra = f == kFaceW ? 1 : 0;
+        if (!t->first_slab(g)) {  // with the slab below: my first planes go down, its last planes come up
+            h.send[0] = base + (size_t)pz * st;
+            h.send_bytes[0] = (size_t)(pz + extra) * st;
+            h.recv[0] = base;
+            h.recv_bytes[0] = (size_t)pz * st;
+        }
+        if (!t->last_slab(g)) {
+            h.send[1] = base + (size_t)nz * st;  // local planes [nz - pz, nz)
+            h.send_bytes[1] = (size_t)pz * st;
+            h.recv[1] = base + (size_t)(nz + pz) * st;
+            h.recv_bytes[1] = (size_t)(pz + extra) * st;
+        }
+    } else {
+        const size_t st = (size_t)g->gf.nx * g->gf.ny * R;
+        char *base = (char *)cell_ptr(g, f);
+        if (!t->first_slab(g)) {
+            h.send[0] = base;
+            h.recv[0] = base - st;
+            h.send_bytes[0] = h.recv_bytes[0] = st;
+        }
+        if (!t->last_slab(g)) {
+            h.send[1] = base + (size_t)(nz - 1) * st;
+            h.recv[1] = base + (size_t)nz * st;
+            h.send_bytes[1] = h.recv_bytes[1] = st;
+        }
+    }
+    return h;
+}
+
+static int team_refresh(GridTeam *t, bool faces, int f) {
+    if (t->kind == 0) {
+        for (size_t i = 0; i + 1 < t->m.size(); i++) {
+            const HaloRuns lo = halo_runs(t, t->m[i], faces, f), hi = halo_runs(t, t->m[i + 1], faces, f);
+            if (lo.send_bytes[1] != hi.recv_bytes[0] || hi.send_bytes[0] != lo.recv_bytes[1])
+                return fail(FSA_ERR_INVALID, "grid team: slabs %zu and %zu disagree about their exchange", i, i + 1);
+            FSA_HIP(hipMemcpyAsync(hi.recv[0], lo.send[1], lo.send_bytes[1], hipMemcpyDeviceToDevice, t->stream));
+            FSA_HIP(hipMemcpyAsync(lo.recv[1], hi.send[0], hi.send_bytes[0], hipMemcpyDeviceToDevice, t->stream));
+        }
+        return FSA_OK;
+    }
+    const HaloRuns h = halo_runs(t, t->m[0], faces, f);
+    if (!h.send[0] && !h.send[1]) return FSA_OK;
+    TEAM_NCCL(ncclGroupStart());
+    ncclResult_t nr = ncclSuccess;
+    for (int d = 0; d < 2 && nr == ncclSuccess; d++) {
+        if (!h.send[d]) continue;
+        const int peer = t->rank + (d == 0 ? -1 : 1);
+        nr = ncclSend(h.send[d], h.send_bytes[d], ncclChar, peer, t->comm, t->stream);
+        if (nr == ncclSuccess) nr = ncclRecv(h.recv[d], h.recv_bytes[d], ncclChar, peer, t->comm, t->stream);
+    }
+    const ncclResult_t ne = ncclGroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return fail(FSA_ERR_HIP, "grid team: RCCL send / receive failed: %s", ncclGetErrorString(nr));
+    return FSA_OK;
+}
+
+static int team_refresh_velocity(GridTeam *t) {
+    for (int f = 0; f < 3; f++) {
+        int rc = team_refresh(t, true, f);
+        if (rc) return rc;
+    }
+    return FSA_OK;
+}
+
+// totals of every slab's block partials at `offset` (slot 0, and slot 1 if `two`) into t->sums, over all processes
+static int team_sums(GridTeam *t, int offset, bool two, const std::vector<int> &nb) {
+    TeamParts tp{};
+    tp.count = (int)t->m.size();
+    for (int i = 0; i < tp.count; i++) {
+        tp.partials[i] = t->m[i]->partials;
+        tp.cg[i] = t->m[i]->cg;
+        tp.nb[i] = nb[i];
+    }
+    hipLaunchKernelGGL(team_sum_kernel, dim3(1), dim3(kBlock), 0, t->stream, tp, offset, two ? 1 : 0, t->sums);
+    FSA_HIP(hipGetLastError());
+    if (t->kind == 1) TEAM_NCCL(ncclAllReduce(t->sums, t->sums, 2, ncclDouble, ncclSum, t->comm, t->stream));
+    return FSA_OK;
+}
+
+static TeamParts team_states(GridTeam *t) {
+    TeamParts tp{};
+    tp.count = (int)t->m.size();
+    for (int i = 0; i < tp.count; i++) tp.cg[i] = t->m[i]->cg;
+    return tp;
+}
+
+#define TEAM_EACH(call)                   \
+    do {                                  \
+        for (GridSolver * g : t->m) {     \
+            int _rc = (call);             \
+            if (_rc) return _rc;          \
+        }                                 \
+    } while (0)
+
+static int team_advect(GridTeam *t) {
+    TEAM_EACH(grid_advect(g));
+    return team_refresh_velocity(t);
+}
+
+static int team_advect_particles(GridTeam *t) {
+    if (t->n_particles == 0) return FSA_OK;
+    const size_t R = t->real_size(), n = (size_t)t->n_particles;
+    if (t->kind == 0) {  // (a tracer nobody claims -- its position is not a number -- stays as it is)
+        FSA_HIP(hipMemcpyAsync(t->pnew, t->ppos, n * 3 * R, hipMemcpyDeviceToDevice, t->stream));
+        FSA_HIP(hipMemcpyAsync(t->pcnew, t->pcolor, n * 4 * R, hipMemcpyDeviceToDevice, t->stream));
+    } else {  // the other ranks' tracers arrive by a sum with zeros
+        FSA_HIP(hipMemsetAsync(t->pnew, 0, n * 3 * R, t->stream));
+        FSA_HIP(hipMemsetAsync(t->pcnew, 0, n * 4 * R, t->stream));
+    }
+    for (GridSolver *g : t->m)
+        GRID_LAUNCH(grid_advect_particles_kernel<T>, gblocks(t->n_particles), G, t->n_particles, (const T *)g->u,
+                    (const T *)g->v, (const T *)g->w, (const T *)t->ppos, (T *)t->pnew, (T *)t->pcnew);
+    if (t->kind == 1) {
+        const ncclDataType_t dt = t->precision == FSA_PRECISION_F64 ? ncclDouble : ncclFloat;
+        TEAM_NCCL(ncclAllReduce(t->pnew, t->pnew, n * 3, dt, ncclSum, t->comm, t->stream));
+        TEAM_NCCL(ncclAllReduce(t->pcnew, t->pcnew, n * 4, dt, ncclSum, t->comm, t->stream));
+    }
+    std::swap(t->ppos, t->pnew);
+    std::swap(t->pcolor, t->pcnew);
+    return FSA_OK;
+}
+
+static int team_div(GridTeam *t, bool with_rhs) {
+    std::vector<int> nb;
+    for (GridSolver *g : t->m) {
+        const int n = rblocks(g->dimSize);
+        nb.push_back(n);
+        if (with_rhs)
+            GRID_LAUNCH((grid_div_kernel<T, true>), n, G, (const T *)g->u, (const T *)g->v, (const T *)g->w, (T *)g->divU,
+                        (T *)g->b, g->partials);
+        else
+            GRID_LAUNCH((grid_div_kernel<T, false>), n, G, (const T *)g->u, (const T *)g->v, (const T *)g->w,
+                        (T *)g->divU, (T *)g->b, g->partials);
+    }
+    return team_sums(t, 0, false, nb);
+}
+
+static int team_update_u(GridTeam *t) {
+    TEAM_EACH(grid_update_u(g));
+    return team_refresh_velocity(t);
+}
+
+static int team_solve(GridTeam *t, int maxiter, int *iters, double *residual, int *rounds) {
+    std::vector<SolvePlan> pl;
+    std::vector<int> nb_dots, nb;
+    for (GridSolver *g : t->m) {
+        pl.push_back(solve_plan(g));
+        nb_dots.push_back(pl.back().nb_dots);
+        nb.push_back(pl.back().nb);
+        hipLaunchKernelGGL(cg_reset_kernel, dim3(1), dim3(1), 0, t->stream, g->cg, maxiter);
+    }
+    const long long cells = (long long)t->dim[0] * t->dim[1] * t->dim[2];
+    const TeamParts states = team_states(t);
+    const int nm = (int)t->m.size();
+    int rc = team_refresh(t, false, kCellP);
+    if (rc) return rc;
+    for (int i = 0; i < nm; i++)
+        if ((rc = launch_cg_init(t->m[i], pl[i]))) return rc;
+    CgState st{};
+    int round = 0;
+    for (;;) {
+        for (int k = 0; k < kCgBatch; k++, round++) {
+            if ((rc = team_refresh(t, false, kCellQ))) return rc;
+            for (int i = 0; i < nm; i++)
+                if ((rc = launch_cg_matvec(t->m[i], pl[i]))) return rc;
+            if ((rc = team_sums(t, 0, true, nb_dots))) return rc;
+            if (t->precision == FSA_PRECISION_F32)
+                hipLaunchKernelGGL(team_alpha_kernel<float>, dim3(1), dim3(64), 0, t->stream, states, t->sums);
+            else
+                hipLaunchKernelGGL(team_alpha_kernel<double>, dim3(1), dim3(64), 0, t->stream, states, t->sums);
+            for (GridSolver *g : t->m)
+                GRID_LAUNCH(cg_update_kernel<T>, rblocks(g->dimSize), G, g->cg, (const T *)g->q, (const T *)g->Aq,
+                            (T *)g->p, (T *)g->r, g->partials);
+            if ((rc = team_sums(t, 2 * kPartials, true, nb))) return rc;
+            if (t->precision == FSA_PRECISION_F32)
+                hipLaunchKernelGGL(team_beta_kernel<float>, dim3(1), dim3(64), 0, t->stream, states, t->sums, (int)cells);
+            else
+                hipLaunchKernelGGL(team_beta_kernel<double>, dim3(1), dim3(64), 0, t->stream, states, t->sums, (int)cells);
+            for (GridSolver *g : t->m)
+                GRID_LAUNCH(cg_direction_kernel<T>, rblocks(g->dimSize), G, g->cg, round, (const T *)g->r, (T *)g->q);
+        }
+        FSA_HIP(hipMemcpyAsync(&st, t->m[0]->cg, sizeof(st), hipMemcpyDeviceToHost, t->stream));
+        FSA_HIP(counted_stream_sync(t->stream));
+        if (st.finished || st.pending) break;
+    }
+    if (st.finished == 2)
+        return fail(FSA_ERR_INVALID, "conjugate gradients: the residual is not a number after %d rounds", st.rounds);
+    if ((rc = team_refresh(t, false, kCellP))) return rc;
+    for (int i = 0; i < nm; i++)
+        if ((rc = launch_mvproduct_p(t->m[i], pl[i]))) return rc;
+    if (iters) *iters = st.iter;
+    if (residual) *residual = st.rabs;
+    if (rounds) *rounds = st.rounds;
+    return FSA_OK;
+}
+
+// A field by name: which of the face / cell arrays
+static bool team_field(const std::string &k, bool *faces, int *f, bool *adv) {
+    *adv = false;
+    const char *fn[] = {"u", "v", "w"};
+    for (int i = 0; i < 3; i++) {
+        if (k == fn[i]) { *faces = true; *f = i; return true; }
+        if (k == std::string(fn[i]) + "adv") { *faces = true; *f = i; *adv = true; return true; }
+    }
+    const char *cn[] = {"p", "divU", "b", "Aq", "r", "q"};
+    for (int i = 0; i < 6; i++)
+        if (k == cn[i]) { *faces = false; *f = i; return true; }
+    return false;
+}
+
+// Copies between a field in the layout of the single solver (the whole grid, `pad` planes of padding in z) and
+// the slabs.  to_host: every slab writes the planes it owns (the first and the last also the padding below and
+// above the domain); else every slab takes all the planes it holds, copies of the neighbours' included.
+static int team_copy_field(GridTeam *t, const char *name, void *host, size_t bytes, bool to_host) {
+    if (!name || (!host && bytes)) return fail(FSA_ERR_INVALID, "NULL argument");
+    bool faces = false, adv = false;
+    int f = 0;
+    if (!team_field(name, &faces, &f, &adv)) return fail(FSA_ERR_UNKNOWN_NAME, "unknown grid field '%s'", name);
+    const size_t R = t->real_size();
+    const int gnz = t->dim[2], pad = t->pad;
+    const int extra = (faces && f == kFaceW) ? 1 : 0;
+    size_t plane = 0, total = 0;
+    if (faces) {
+        plane = face_plane(t->m[0], f) * R;
+        total = plane * (size_t)(gnz + 2 * pad + extra);
+    } else {
+        plane = (size_t)t->dim[0] * t->dim[1] * R;
+        total = plane * (size_t)gnz;
+    }
+    if (bytes != total) return fail(FSA_ERR_INVALID, "field '%s' is %zu bytes, caller passed %zu", name, total, bytes);
+    FSA_HIP(counted_stream_sync(t->stream));
+    for (GridSolver *g : t->m) {
+        const int nz = g->gf.nz;
+        // local planes [lo, hi) and the array's plane index of local plane 0; global plane = kz0 + gpad + local
+        int lo, hi, base0;
+        const int gpad = faces ? pad : 0, gtop = gnz + 2 * gpad + extra;  // planes of the whole-grid array
+        char *dev;
+        if (faces) {
+            void *arr[] = {adv ? g->uadv : g->u, adv ? g->vadv : g->v, adv ? g->wadv : g->w};
+            dev = (char *)arr[f];
+            base0 = t->padz;
+            if (to_host) {
+                lo = t->first_slab(g) ? -pad : 0;
+                hi = nz + (t->last_slab(g) ? pad + extra : 0);
+            } else {
+                lo = -t->padz;
+                hi = nz + t->padz + extra;
+            }
+        } else {
+            dev = (char *)cell_ptr(g, f);
+            base0 = 0;
+            lo = to_host ? 0 : -1;
+            hi = to_host ? nz : nz + 1;
+        }
+        lo = std::max(lo, -(g->kz0 + gpad));
+        hi = std::min(hi, gtop - (g->kz0 + gpad));
+        if (hi <= lo) continue;
+        char *d = dev + (ptrdiff_t)(lo + base0) * (ptrdiff_t)plane;
+        char *h = (char *)host + (size_t)(g->kz0 + gpad + lo) * plane;
+        const size_t nbytes = (size_t)(hi - lo) * plane;
+        if (to_host) FSA_HIP(hipMemcpy(h, d, nbytes, hipMemcpyDeviceToHost));
+        else FSA_HIP(hipMemcpy(d, h, nbytes, hipMemcpyHostToDevice));
+    }
+    return FSA_OK;
+}
+
+static int team_make(const int dim[3], int padding, double h, double dt, double rho, int precision, int device, int kind,
+                     int rank, int world, const int *cuts, int reach, GridTeam **out) {
+    int rc = grid_check_args(dim, padding, h, dt, rho, precision, device);
+    if (rc) return rc;
+    if (world < 1 || world > kMaxTeam || !cuts || reach < 1 || rank < 0 || rank >= world)
+        return fail(FSA_ERR_INVALID, "grid team: 1 to %d slabs, a reach of at least one plane", kMaxTeam);
+    const int padz = std::max(padding, reach + 1);
+    if (cuts[0] != 0 || cuts[world] != dim[2]) return fail(FSA_ERR_INVALID, "grid team: the cuts must span the planes 0 .. %d", dim[2]);
+    for (int r = 0; r < world; r++)
+        if (world > 1 && cuts[r + 1] - cuts[r] < padz + 1)
+            return fail(FSA_ERR_INVALID, "grid team: slab %d has %d planes, fewer than reach + 2 = %d", r, cuts[r + 1] - cuts[r],
+                        padz + 1);
+    GridTeam *t = new (std::nothrow) GridTeam();
+    if (!t) return fail(FSA_ERR_NOMEM, "out of host memory");
+    t->kind = kind;
+    t->world = world;
+    t->rank = rank;
+    for (int a = 0; a < 3; a++) t->dim[a] = dim[a];
+    t->pad = padding;
+    t->padz = padz;
+    t->precision = precision;
+    t->device = device;
+    t->cuts.assign(cuts, cuts + world + 1);
+    rc = FSA_OK;
+    if (hipSetDevice(device) != hipSuccess) rc = fail(FSA_ERR_HIP, "hipSetDevice failed");
+    if (rc == FSA_OK && hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(FSA_ERR_HIP, "hipStreamCreate failed");
+    if (rc == FSA_OK) rc = galloc((void **)&t->err, 4 * sizeof(int));
+    if (rc == FSA_OK) rc = galloc((void **)&t->sums, 2 * sizeof(double));
+    const int r0 = kind == 0 ? 0 : rank, r1 = kind == 0 ? world : rank + 1;
+    for (int r = r0; r < r1 && rc == FSA_OK; r++) {
+        GridSolver *g = nullptr;
+        rc = grid_make(dim, padding, h, dt, rho, precision, device, cuts[r], cuts[r + 1] - cuts[r], padz, t->err, t->stream,
+                       &g);
+        if (rc == FSA_OK) t->m.push_back(g);
+    }
+    if (rc != FSA_OK) {
+        team_free(t);
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return FSA_OK;
 }
 
 }  // namespace fsa
@@ -886,47 +1450,11 @@ int fsa_grid_create(const int dim[3], int padding, double h, double dt, double r
                     fsa_grid **out) {
     if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (!dim || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0) return fail(FSA_ERR_INVALID, "dim must be positive");
-    // the advection reads one face outside the effective grid on every side
-    if (padding < 1) return fail(FSA_ERR_INVALID, "padding %d: at least 1 is needed", padding);
-    if (!(h > 0) || !(dt > 0) || !(rho > 0)) return fail(FSA_ERR_INVALID, "h, dt and rho must be positive");
-    if (precision != FSA_PRECISION_F32 && precision != FSA_PRECISION_F64)
-        return fail(FSA_ERR_INVALID, "unknown precision %d", precision);
-    const double faces = ((double)dim[0] + 2 * padding + 1) * ((double)dim[1] + 2 * padding + 1) *
-                         ((double)dim[2] + 2 * padding + 1);
-    if (faces >= 2147483647.0) return fail(FSA_ERR_INVALID, "grid too large for 32-bit face indices");
-    int ndev = 0;
-    FSA_HIP(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(FSA_ERR_INVALID, "device %d of %d", device, ndev);
-    GridSolver *g = new (std::nothrow) GridSolver();
-    if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
-    g->precision = precision;
-    g->device = device;
-    fill_dev(g, g->gf, dim, padding, h, dt, rho);
-    fill_dev(g, g->gd, dim, padding, h, dt, rho);
-    g->uSize = g->gf.ulen * g->gf.ylen * g->gf.zlen;
-    g->vSize = g->gf.xlen * g->gf.vlen * g->gf.zlen;
-    g->wSize = g->gf.xlen * g->gf.ylen * g->gf.wlen;
-    g->dimSize = g->gf.dimSize;
-    int rc = FSA_OK;
-    if (hipSetDevice(device) != hipSuccess) rc = fail(FSA_ERR_HIP, "hipSetDevice failed");
-    if (rc == FSA_OK && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess)
-        rc = fail(FSA_ERR_HIP, "hipStreamCreate failed");
-    const size_t R = g->real_size();
-    void **face[] = {&g->u, &g->v, &g->w, &g->uadv, &g->vadv, &g->wadv};
-    const size_t face_n[] = {(size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize,
-                             (size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize};
-    for (int k = 0; k < 6 && rc == FSA_OK; k++) rc = galloc(face[k], face_n[k] * R);
-    void **cell[] = {&g->p, &g->divU, &g->b, &g->Aq, &g->r, &g->q};
-    for (int k = 0; k < 6 && rc == FSA_OK; k++) rc = galloc(cell[k], (size_t)g->dimSize * R);
-    if (rc == FSA_OK) rc = galloc((void **)&g->partials, 4 * kPartials * sizeof(double));
-    if (rc == FSA_OK) rc = galloc((void **)&g->cg, sizeof(CgState));
-    if (rc == FSA_OK) rc = galloc((void **)&g->divsum, sizeof(double));
-    if (rc != FSA_OK) {
-        grid_free(g);
-        delete g;
-        return rc;
-    }
+    int rc = grid_check_args(dim, padding, h, dt, rho, precision, device);
+    if (rc) return rc;
+    GridSolver *g = nullptr;
+    rc = grid_make(dim, padding, h, dt, rho, precision, device, 0, dim[2], padding, nullptr, nullptr, &g);
+    if (rc) return rc;
     *out = reinterpret_cast<fsa_grid *>(g);
     return FSA_OK;
 }
@@ -1133,6 +1661,188 @@ int fsa_grid_step(fsa_grid *hg, int nsteps, int maxiter) {
         GTRY(grid_div(g, false));
         g->frame++;
     }
+    return FSA_OK;
+}
+
+// ---- grid team ------------------------------------------------------------------------------------------
+#define TNEED(t)                                                      \
+    do {                                                              \
+        if (!(t)) return fail(FSA_ERR_INVALID, "grid team is NULL");  \
+        FSA_HIP(hipSetDevice((t)->device));                           \
+    } while (0)
+
+int fsa_grid_team_create_local(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                               int world, const int *cuts, int reach, fsa_grid_team **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    GridTeam *t = nullptr;
+    int rc = team_make(dim, padding, h, dt, rho, precision, device, 0, 0, world, cuts, reach, &t);
+    if (rc) return rc;
+    *out = reinterpret_cast<fsa_grid_team *>(t);
+    return FSA_OK;
+}
+
+int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                              int rank, int world, const char id[FSA_SLAB_GROUP_ID_BYTES], const int *cuts, int reach,
+                              fsa_grid_team **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!id) return fail(FSA_ERR_INVALID, "id is NULL");
+    GridTeam *t = nullptr;
+    int rc = team_make(dim, padding, h, dt, rho, precision, device, 1, rank, world, cuts, reach, &t);
+    if (rc) return rc;
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    const ncclResult_t r = ncclCommInitRank(&t->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        t->comm = nullptr;
+        team_free(t);
+        delete t;
+        return fail(FSA_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    }
+    *out = reinterpret_cast<fsa_grid_team *>(t);
+    return FSA_OK;
+}
+
+int fsa_grid_team_destroy(fsa_grid_team *ht) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    if (!t) return FSA_OK;
+    team_free(t);
+    delete t;
+    return FSA_OK;
+}
+
+int fsa_grid_team_get_field(fsa_grid_team *ht, const char *name, void *dst, size_t bytes) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_copy_field(t, name, dst, bytes, true);
+}
+
+int fsa_grid_team_set_field(fsa_grid_team *ht, const char *name, const void *src, size_t bytes) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_copy_field(t, name, const_cast<void *>(src), bytes, false);
+}
+
+int fsa_grid_team_set_particles(fsa_grid_team *ht, int n, const void *pos3) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    if (n < 0 || (n > 0 && !pos3)) return fail(FSA_ERR_INVALID, "bad particle array");
+    FSA_HIP(counted_stream_sync(t->stream));
+    const size_t R = t->real_size();
+    if (n > t->particle_cap) {
+        void **arr[] = {&t->ppos, &t->pcolor, &t->pnew, &t->pcnew};
+        for (void **a : arr) {
+            if (*a) (void)hipFree(*a);
+            *a = nullptr;
+        }
+        t->particle_cap = 0;
+        GTRY(galloc(&t->ppos, (size_t)n * 3 * R));
+        GTRY(galloc(&t->pnew, (size_t)n * 3 * R));
+        GTRY(galloc(&t->pcolor, (size_t)n * 4 * R));
+        GTRY(galloc(&t->pcnew, (size_t)n * 4 * R));
+        t->particle_cap = n;
+    }
+    t->n_particles = n;
+    if (n == 0) return FSA_OK;
+    FSA_HIP(hipMemcpy(t->ppos, pos3, (size_t)n * 3 * R, hipMemcpyHostToDevice));
+    if (t->precision == FSA_PRECISION_F32) {  // addParticles :635: colour (1, 1, 1, 1)
+        std::vector<float> one((size_t)n * 4, 1.f);
+        FSA_HIP(hipMemcpy(t->pcolor, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        std::vector<double> one((size_t)n * 4, 1.0);
+        FSA_HIP(hipMemcpy(t->pcolor, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return FSA_OK;
+}
+
+int fsa_grid_team_get_particles(fsa_grid_team *ht, void *pos3, void *color4, int *n) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    if (n) *n = t->n_particles;
+    FSA_HIP(counted_stream_sync(t->stream));
+    const size_t R = t->real_size(), N = (size_t)t->n_particles;
+    if (N == 0) return FSA_OK;
+    if (pos3) FSA_HIP(hipMemcpy(pos3, t->ppos, N * 3 * R, hipMemcpyDeviceToHost));
+    if (color4) FSA_HIP(hipMemcpy(color4, t->pcolor, N * 4 * R, hipMemcpyDeviceToHost));
+    return FSA_OK;
+}
+
+int fsa_grid_team_advect(fsa_grid_team *ht) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_advect(t);
+}
+
+int fsa_grid_team_advect_particles(fsa_grid_team *ht) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_advect_particles(t);
+}
+
+int fsa_grid_team_body_force(fsa_grid_team *ht) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    TEAM_EACH(grid_body_force(g));
+    return FSA_OK;
+}
+
+int fsa_grid_team_make_rhs(fsa_grid_team *ht) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_div(t, true);
+}
+
+int fsa_grid_team_div_velocity(fsa_grid_team *ht, double *div_u_sum) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    GTRY(team_div(t, false));
+    if (div_u_sum) {
+        FSA_HIP(hipMemcpyAsync(div_u_sum, t->sums, sizeof(double), hipMemcpyDeviceToHost, t->stream));
+        FSA_HIP(counted_stream_sync(t->stream));
+    }
+    return FSA_OK;
+}
+
+int fsa_grid_team_solve(fsa_grid_team *ht, int maxiter, int *iterations, double *residual) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_solve(t, maxiter, iterations, residual, nullptr);
+}
+
+int fsa_grid_team_update_u(fsa_grid_team *ht) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    return team_update_u(t);
+}
+
+int fsa_grid_team_step(fsa_grid_team *ht, int nsteps, int maxiter) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    for (int k = 0; k < nsteps; k++) {  // Step :608-619
+        GTRY(team_advect(t));
+        GTRY(team_advect_particles(t));
+        TEAM_EACH(grid_body_force(g));
+        GTRY(team_div(t, true));
+        GTRY(team_solve(t, maxiter, nullptr, nullptr, nullptr));
+        GTRY(team_update_u(t));
+        GTRY(team_div(t, false));
+        t->frame++;
+    }
+    return FSA_OK;
+}
+
+int fsa_grid_team_sync(fsa_grid_team *ht, int *error_bits) {
+    GridTeam *t = reinterpret_cast<GridTeam *>(ht);
+    TNEED(t);
+    FSA_HIP(counted_stream_sync(t->stream));
+    int err = 0;
+    FSA_HIP(hipMemcpy(&err, t->err, sizeof(int), hipMemcpyDeviceToHost));
+    if (error_bits) *error_bits = err;
+    if (err)
+        return fail(FSA_ERR_CAPACITY, "grid team: a sample of the velocity needed a plane that its slab does not hold (a "
+                                      "back-trace crossed more planes than the team's reach); the state is invalid");
     return FSA_OK;
 }
 

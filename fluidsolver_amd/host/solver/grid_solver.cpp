@@ -2,6 +2,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 #include "xml_lite.h"
 
@@ -16,6 +18,7 @@ void check(int rc, const char *what) {
 
 GridSolver::~GridSolver() {
     if (device) fsa_grid_destroy(device);
+    if (team) fsa_grid_team_destroy(team);
 }
 
 // setup, solver/grid_solver.cpp:5-12
@@ -58,11 +61,27 @@ void GridSolver::loadConfig() {
 }
 
 // allocate :42-66: every field on the device, cleared
+// FSA_GRID_SLABS=N (this build): the grid as a team of N z-slabs of equal thickness on the one GPU, a rehearsal
+// of the one-slab-per-GPU form with the same results; FSA_GRID_REACH = planes a back-trace may cross (default 1).
 void GridSolver::allocate() {
     if (device) fsa_grid_destroy(device);
+    if (team) fsa_grid_team_destroy(team);
     device = nullptr;
+    team = nullptr;
     const int dim[3] = {grid.dim.x, grid.dim.y, grid.dim.z};
     const char *dev = std::getenv("FSA_DEVICE");
+    const char *slabs = std::getenv("FSA_GRID_SLABS");
+    const int n = slabs ? std::atoi(slabs) : 0;
+    if (n > 1) {
+        const char *r = std::getenv("FSA_GRID_REACH");
+        std::vector<int> cuts((size_t)n + 1);
+        for (int k = 0; k <= n; k++) cuts[(size_t)k] = (int)((long long)k * dim[2] / n);
+        check(fsa_grid_team_create_local(dim, grid.padding, grid.h, dt, rho, FSA_PRECISION_F32, dev ? std::atoi(dev) : 0, n,
+                                         cuts.data(), r ? std::atoi(r) : 1, &team),
+              "fsa_grid_team_create_local");
+        std::printf("grid on %d z-slabs\n", n);
+        return;
+    }
     check(fsa_grid_create(dim, grid.padding, grid.h, dt, rho, FSA_PRECISION_F32, dev ? std::atoi(dev) : 0, &device),
           "fsa_grid_create");
 }
@@ -77,38 +96,54 @@ void GridSolver::addParticles() {
                 color.push_back(cfloat4(1, 1, 1, 1));
             }
     numParticles = (int)pos.size();
-    check(fsa_grid_set_particles(device, numParticles, pos.data()), "fsa_grid_set_particles");
+    if (team) check(fsa_grid_team_set_particles(team, numParticles, pos.data()), "fsa_grid_team_set_particles");
+    else check(fsa_grid_set_particles(device, numParticles, pos.data()), "fsa_grid_set_particles");
 }
 
 void GridSolver::readBackParticles() {
     int n = 0;
+    if (team) {
+        check(fsa_grid_team_sync(team, nullptr), "grid team");  // (a back-trace beyond the reach ends the program)
+        check(fsa_grid_team_get_particles(team, pos.data(), color.data(), &n), "fsa_grid_team_get_particles");
+        return;
+    }
     check(fsa_grid_get_particles(device, pos.data(), color.data(), &n), "fsa_grid_get_particles");
 }
 
-void GridSolver::testcase() { check(fsa_grid_testcase(device), "testcase"); }
+void GridSolver::testcase() {
+    if (team) {
+        std::fprintf(stderr, "testcase: not available on z-slabs (FSA_GRID_SLABS)\n");
+        std::exit(EXIT_FAILURE);
+    }
+    check(fsa_grid_testcase(device), "testcase");
+}
 
 void GridSolver::divVelocity() {
     double s = 0.0;
-    check(fsa_grid_div_velocity(device, &s), "divVelocity");
+    check(team ? fsa_grid_team_div_velocity(team, &s) : fsa_grid_div_velocity(device, &s), "divVelocity");
     divUsum = (scalar)s;
     std::printf("div sum %f\n", divUsum);
 }
 
-void GridSolver::makeRHS() { check(fsa_grid_make_rhs(device), "makeRHS"); }
+void GridSolver::makeRHS() { check(team ? fsa_grid_team_make_rhs(team) : fsa_grid_make_rhs(device), "makeRHS"); }
 
 void GridSolver::solve() {
-    check(fsa_grid_solve(device, max_cg_iterations, &last_cg_iterations, &last_cg_residual), "solve");
+    check(team ? fsa_grid_team_solve(team, max_cg_iterations, &last_cg_iterations, &last_cg_residual)
+               : fsa_grid_solve(device, max_cg_iterations, &last_cg_iterations, &last_cg_residual),
+          "solve");
     std::printf("turn %d residual: %f\n", last_cg_iterations, last_cg_residual);
 }
 
 void GridSolver::updateU() {
-    check(fsa_grid_update_u(device), "updateU");
+    check(team ? fsa_grid_team_update_u(team) : fsa_grid_update_u(device), "updateU");
     std::printf("time step size updated as %f.\n", dt);
 }
 
-void GridSolver::bodyForce() { check(fsa_grid_body_force(device), "bodyForce"); }
-void GridSolver::advect() { check(fsa_grid_advect(device), "advect"); }
-void GridSolver::advectParticles() { check(fsa_grid_advect_particles(device), "advectParticles"); }
+void GridSolver::bodyForce() { check(team ? fsa_grid_team_body_force(team) : fsa_grid_body_force(device), "bodyForce"); }
+void GridSolver::advect() { check(team ? fsa_grid_team_advect(team) : fsa_grid_advect(device), "advect"); }
+void GridSolver::advectParticles() {
+    check(team ? fsa_grid_team_advect_particles(team) : fsa_grid_advect_particles(device), "advectParticles");
+}
 
 // Step :608-619
 void GridSolver::Step() {
@@ -126,11 +161,12 @@ void GridSolver::Step() {
 void GridSolver::HandleKeyEvent(char) {}
 
 std::vector<scalar> GridSolver::field(const char *name) {
-    int sizes[4] = {0, 0, 0, 0};
-    check(fsa_grid_sizes(device, sizes, nullptr), "fsa_grid_sizes");
+    // Grid::setSize, solver/grid_solver.h:23-35
+    const int sizes[4] = {grid.uSize, grid.vSize, grid.wSize, grid.dimSize};
     const std::string k(name);
     const int n = k[0] == 'u' ? sizes[0] : k[0] == 'v' ? sizes[1] : k[0] == 'w' ? sizes[2] : sizes[3];
-    std::vector<scalar> out((size_t)n);
-    check(fsa_grid_get_field(device, name, out.data(), out.size() * sizeof(scalar)), "fsa_grid_get_field");
+    std::vector<scalar> out((size_t)n, (scalar)0);
+    if (team) check(fsa_grid_team_get_field(team, name, out.data(), out.size() * sizeof(scalar)), "fsa_grid_team_get_field");
+    else check(fsa_grid_get_field(device, name, out.data(), out.size() * sizeof(scalar)), "fsa_grid_get_field");
     return out;
 }

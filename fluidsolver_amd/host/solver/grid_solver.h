@@ -80,5 +80,6 @@ public:
 
 private:
     fsa_grid *device = nullptr;
+    fsa_grid_team *team = nullptr;  // FSA_GRID_SLABS=N: the grid as N z-slabs instead
     void readBackParticles();
 };

@@ -556,6 +556,52 @@ int fsa_grid_dotproduct(fsa_grid *g, const char *a, const char *b, double *out);
 /* nsteps x GridSolver::Step :608-619 */
 int fsa_grid_step(fsa_grid *g, int nsteps, int maxiter);
 
+/* ------------------------------------------------------------------------------------------------
+ * The grid solver on z-slabs (no counterpart in the reference, whose GridSolver is one grid on one host:
+ * solver/grid_solver.cpp).  The grid is cut into slabs of whole z planes, cuts[0] = 0 < ... < cuts[world] =
+ * dim[2], one solver per slab.  A slab keeps copies of its neighbours' planes: `reach` + 1 planes of the face
+ * arrays (refreshed after the advection and after the velocity update; `reach` is how many planes the
+ * back-trace of the advection may cross: a sample that needs more raises an error bit that fsa_grid_team_sync
+ * reports, and the state is then invalid), one plane of p and of the search direction q (refreshed before
+ * every stencil of the conjugate-gradient loop).  The two dot products and the residual of a round and the
+ * divergence sum are totals over all slabs, so every slab runs the same rounds.  Every slab needs at least
+ * max(padding, reach + 1) + 1 planes; at most 16 slabs.
+ *
+ * fsa_grid_team_create_local: all slabs in this process, on one GPU and one stream (refreshes are device
+ * copies); fsa_grid_team_create_rccl: this process holds slab `rank` of `world` (one process per GPU), refreshes
+ * are ncclSend / ncclRecv with the two z-neighbours and the totals an ncclAllReduce of two doubles, all queued
+ * on the team's stream; `id` comes from fsa_slab_group_unique_id on rank 0.  Tracer arrays are whole on every
+ * rank (each moves the tracers inside its planes; the rest arrives by an all-reduce with zeros).
+ *
+ * Fields are exchanged with the caller in the layout of the single solver (fsa_grid_get_field, the whole
+ * grid): get fills the planes this process's slabs own and leaves the rest of dst alone (a local team fills
+ * all of it), set takes what its slabs hold, copies of the neighbours' planes included.  Cell-centred results
+ * and velocities equal the single solver's bit for bit as long as the totals round to the same number in the
+ * solver's precision (they are added up in double in another order: always, in practice, for fp32; to 1e-10
+ * for fp64).  The other calls are the team's forms of the fsa_grid_* calls of the same name.
+ */
+typedef struct fsa_grid_team fsa_grid_team;
+int fsa_grid_team_create_local(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                               int world, const int *cuts, int reach, fsa_grid_team **out);
+int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                              int rank, int world, const char id[FSA_SLAB_GROUP_ID_BYTES], const int *cuts, int reach,
+                              fsa_grid_team **out);
+int fsa_grid_team_destroy(fsa_grid_team *t);
+int fsa_grid_team_get_field(fsa_grid_team *t, const char *name, void *dst, size_t bytes); /* synchronises */
+int fsa_grid_team_set_field(fsa_grid_team *t, const char *name, const void *src, size_t bytes);
+int fsa_grid_team_set_particles(fsa_grid_team *t, int n, const void *pos3);
+int fsa_grid_team_get_particles(fsa_grid_team *t, void *pos3, void *color4, int *n); /* synchronises */
+int fsa_grid_team_advect(fsa_grid_team *t);
+int fsa_grid_team_advect_particles(fsa_grid_team *t);
+int fsa_grid_team_body_force(fsa_grid_team *t);
+int fsa_grid_team_make_rhs(fsa_grid_team *t);
+int fsa_grid_team_div_velocity(fsa_grid_team *t, double *div_u_sum);
+int fsa_grid_team_solve(fsa_grid_team *t, int maxiter, int *iterations, double *residual);
+int fsa_grid_team_update_u(fsa_grid_team *t);
+int fsa_grid_team_step(fsa_grid_team *t, int nsteps, int maxiter);
+/* waits for the team's stream; *error_bits (may be NULL): 1 = a sample needed a plane its slab does not hold */
+int fsa_grid_team_sync(fsa_grid_team *t, int *error_bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -396,6 +396,22 @@ def test_headless_grid_solver_matches_python_binding(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "bin", "grid_solver")), reason="host layer not built")
+@pytest.mark.parametrize("slabs", [2, 4])
+def test_headless_grid_solver_on_slabs_equals_the_single_grid(tmp_path, slabs):
+    """FSA_GRID_SLABS=N: the plugin class on a team of z-slabs writes the same file, byte for byte"""
+    e = dict(os.environ, FSA_CONFIG_DIR=os.path.join(HOST, "config"))
+    exe = os.path.join(HOST, "bin", "grid_solver")
+    a, b = tmp_path / "one.bin", tmp_path / "slabs.bin"
+    subprocess.check_call([exe, "--frames", "4", "--save-final", str(a)], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    out = subprocess.run([exe, "--frames", "4", "--save-final", str(b)], env=dict(e, FSA_GRID_SLABS=str(slabs)),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert f"grid on {slabs} z-slabs" in out.stdout
+    assert a.read_bytes() == b.read_bytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not have_bins(), reason="host layer not built")
 def test_run_mode_tag_of_the_scene_selects_the_step(tmp_path):
     """<RunMode> IISPH </RunMode> inside the scene does what FSA_RUN_MODE=IISPH does; an unknown word fails loudly"""
