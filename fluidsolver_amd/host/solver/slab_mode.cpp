@@ -16,6 +16,7 @@ namespace {
 
 constexpr int kHalo = 2;
 constexpr unsigned kUndef = 99999999u;
+double g_headroom = 1.5;  // FSA_SLAB_HEADROOM as the slabs were made with (for the message when one is outgrown)
 
 // cell layer (z index) of a position with the arithmetic of calcGridPos / calcHashD
 // (solver/sph_kernel_impl.cuh:74-100): fp32 subtract, divide, floor; -1 outside the domain
@@ -134,9 +135,12 @@ void SPHSolver::EnterSlabMode(int nslabs) {
     // head room over the fullest slab's present count: the slabs are not re-cut during a run, so a scene whose mass
     // moves along z needs more (FSA_SLAB_HEADROOM, default 1.5; an outgrown slab ends the run with FSA_ERR_CAPACITY)
     double headroom = 1.5;
+    long long spare = 4096;  // particles on top of the factor (FSA_SLAB_SPARE; small scenes jiggle by more than a factor covers)
     if (const char *e = std::getenv("FSA_SLAB_HEADROOM")) headroom = std::max(1.0, std::atof(e));
-    const long long capacity64 = (long long)((double)most * headroom) + outside + 4096;
-    const long long record_cap64 = (long long)((double)widest * headroom) + 4096;
+    if (const char *e = std::getenv("FSA_SLAB_SPARE")) spare = std::max(0LL, std::atoll(e));
+    g_headroom = headroom;
+    const long long capacity64 = (long long)((double)most * headroom) + outside + spare;
+    const long long record_cap64 = (long long)((double)widest * headroom) + spare;
     if (capacity64 > 2000000000LL || record_cap64 > 2000000000LL) {
         std::fprintf(stderr, "FSA_SLABS=%d: a slab would hold %lld particles, more than one solver takes; use more slabs\n", nslabs,
                      capacity64);
@@ -296,7 +300,13 @@ void SPHSolver::StepSlabs() {
 void SPHSolver::CopyPosColorFromSlabs() {
     fsa_slab_group_stats st{};
     if (slab_team) check(fsa_slab_iisph_stats(slab_team, nullptr, &st.lost, nullptr, nullptr, 0), "fsa_slab_iisph_stats");
-    else check(fsa_slab_group_sync(slab_group, &st), "fsa_slab_group_sync");
+    else {
+        const int rc = fsa_slab_group_sync(slab_group, &st);
+        if (rc == FSA_ERR_CAPACITY)
+            std::fprintf(stderr, "FSA_SLABS: the slabs are sized when the run starts and not re-cut; raise FSA_SLAB_HEADROOM "
+                                 "(now %.2f) for a scene whose mass moves along z\n", g_headroom);
+        check(rc, "fsa_slab_group_sync");
+    }
     struct Item {
         unsigned long long cell;
         cfloat3 pos;

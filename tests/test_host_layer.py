@@ -211,6 +211,20 @@ def test_headless_program_on_slabs_equals_single_solver(tmp_path, slabs):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not have_bins(), reason="host layer not built")
+def test_headless_program_ends_loudly_when_a_slab_outgrows_its_capacity(tmp_path):
+    """the slabs of FSA_SLABS are sized at the start and never re-cut: with no head room at all (factor 1, no spare
+    particles) the first slab that gains a particle ends the run at the next read-back, non-zero, naming the switch"""
+    exe = os.path.join(HOST, "bin", "particle_solver")
+    e = dict(env_for(20), FSA_SLABS="3", FSA_SLAB_HEADROOM="1.0", FSA_SLAB_SPARE="0")
+    r = subprocess.run([exe, "--frames", "200", "--save-final", str(tmp_path / "x.bin")], env=e, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert "FSA_SLAB_HEADROOM" in r.stderr and "outgrew" in r.stderr
+    assert not (tmp_path / "x.bin").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_bins(), reason="host layer not built")
 def test_corrupted_checkpoint_is_refused(tmp_path):
     """ids outside 0 .. n-1, repeated ids, a particle count far beyond the file and a truncated file: each must end
     in "malformed checkpoint" and leave the set-up scene running, not write through a bad index"""
