@@ -572,12 +572,16 @@ __global__ __launch_bounds__(kBlock) void cg_matvec_march_kernel(GridDev<T> G, c
     if (kbeg < kend) {  // the same for the whole block
         const size_t rowq = (size_t)qx, planeq = rowq * (size_t)G.ny;
         size_t Q = (size_t)kbeg * planeq + (size_t)(active ? j : 0) * rowq + (size_t)qc;
-        Quad<T> zm = (active && kbeg + G.kz0 > 0) ? q4[Q - planeq] : zero;
-        Quad<T> c = active ? q4[Q] : zero;
+        // (plain ifs: `cond ? q4[..] : zero` selects between a global and a private address when the compiler
+        // keeps `zero` in memory, and every load of the loop becomes a flat load beside a scratch store)
+        Quad<T> zm = zero, c = zero;
+        if (active && kbeg + G.kz0 > 0) zm = q4[Q - planeq];
+        if (active) c = q4[Q];
         for (int k = kbeg; k < kend; k++, Q += planeq) {
             const int buf = (k - kbeg) & 1;
-            const Quad<T> zp = (active && k + 1 + G.kz0 < G.gnz) ? q4[Q + planeq] : zero;
-            const Quad<T> rv = active ? r4[Q] : zero;
+            Quad<T> zp = zero, rv = zero;
+            if (active && k + 1 + G.kz0 < G.gnz) zp = q4[Q + planeq];
+            if (active) rv = r4[Q];
             Quad<T> ym = zero, yp = zero;
             if (active && first_row && j > 0) ym = q4[Q - rowq];
             if (active && last_row && j < G.ny - 1) yp = q4[Q + rowq];
@@ -1003,9 +1007,9 @@ static int grid_make(const int dim[3], int padding, double h, double dt, double 
     const size_t face_n[] = {(size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize,
                              (size_t)g->uSize, (size_t)g->vSize, (size_t)g->wSize};
     for (int k = 0; k < 6 && rc == FSA_OK; k++) rc = galloc(face[k], face_n[k] * R);
-    // cell arrays: one plane before and one after (zero; a slab's copies of its neighbours' planes go there)
+    // cell arrays; a slab's have one plane before and one after for the copies of its neighbours' planes
     void **cell[] = {&g->p, &g->divU, &g->b, &g->Aq, &g->r, &g->q};
-    const size_t plane = (size_t)dim[0] * dim[1];
+    const size_t plane = nz == dim[2] && kz0 == 0 && !err ? 0 : (size_t)dim[0] * dim[1];
     for (int k = 0; k < 6 && rc == FSA_OK; k++) {
         rc = galloc(&g->cell_base[k], ((size_t)g->dimSize + 2 * plane) * R);
         if (rc == FSA_OK) *cell[k] = (char *)g->cell_base[k] + plane * R;
