@@ -841,6 +841,32 @@ def bench_distributed(args, build_scene):
         os.close(saved_stdout)
 
 
+class _Watchdog:
+    """Ends the process (status 124) when a phase of the multi-rank bench makes no progress for `limit` seconds: a send
+    without its receive would otherwise leave every rank waiting inside the library for good.  A thread, because a
+    signal handler does not run while the main thread waits inside a library call."""
+
+    def __init__(self, rank, limit):
+        import threading
+        self.rank, self.limit, self.phase, self.deadline = rank, limit, "start", time.monotonic() + limit
+        self.done = threading.Event()
+        if limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def kick(self, phase):
+        self.phase, self.deadline = phase, time.monotonic() + self.limit
+
+    def stop(self):
+        self.done.set()
+
+    def _run(self):
+        while not self.done.wait(1.0):
+            if time.monotonic() > self.deadline:
+                print(f"rank {self.rank}: no progress for {self.limit:.0f} s in phase '{self.phase}' of the slab bench; "
+                      "giving up", file=sys.stderr, flush=True)
+                os._exit(124)
+
+
 def _bench_distributed(args, build_scene):
     import torch
     import torch.distributed as dist
@@ -848,6 +874,7 @@ def _bench_distributed(args, build_scene):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    dog = _Watchdog(rank, float(os.environ.get("FSA_BENCH_WATCHDOG", "600")))
     ndev = torch.cuda.device_count()
     assert ndev > 0, "bench.py needs a GPU"
     device_index = local % ndev
@@ -908,6 +935,7 @@ def _bench_distributed(args, build_scene):
         sc = build_scene(args.scene, 0.0, z_select=lambda z: (layer_of(z) >= lo) & (layer_of(z) < hi))
         n = sc["n_total"]
     n_fluid = sc["n_fluid"]
+    dog.kick("solver and group set-up")
     transport = NeighbourTransport(rank, world, device, group=record_group)
     # With a GPU per rank the step runs in the library's slab group: pack, ncclSend / ncclRecv, unpack and the
     # solver's step queued without a host round trip.  Ranks sharing a card (rehearsal) keep the torch transport.
@@ -993,9 +1021,12 @@ def _bench_distributed(args, build_scene):
         dist.all_reduce(t)
         torch.cuda.synchronize()
 
+    dog.kick("spin-up")
     run(args.spinup)
+    dog.kick("warm-up")
     run(args.warmup)
     barrier()
+    dog.kick("timed steps")
     ss.backend.solver.timing_enable(True)
     ss.backend.solver.timing_reset()
     run.timing = True
@@ -1009,6 +1040,7 @@ def _bench_distributed(args, build_scene):
     host_waits = capi.load().fsa_debug_host_waits() - host_waits0
     barrier()
     wall = time.perf_counter() - t0
+    dog.kick("statistics")
     kt = ss.backend.solver.timing_read()
     for name, (c, ms) in run.kernels.items():
         c0, m0 = kt.get(name, (0, 0.0))
@@ -1044,4 +1076,5 @@ def _bench_distributed(args, build_scene):
     ss.close()
     dist.barrier()
     dist.destroy_process_group()
+    dog.stop()
     return res
