@@ -1408,6 +1408,13 @@ int fsa_debug_time_pass(fsa_solver *hs, int which, int ablate, int reps) {
     return debug_time_pass(s, which, ablate, reps);
 }
 
+// Not part of the public header: the density pass and the force replay in one launch (tools/overlap_probe.py).
+int fsa_debug_fused_probe(fsa_solver *hs, int mode) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    return launch_fused_probe(s, mode);
+}
+
 int fsa_set_variant(fsa_solver *hs, int variant) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");

@@ -226,6 +226,7 @@ int ensure_lists(Solver *s);  // builds the neighbour lists if they are enabled 
 int launch_density_tuned(Solver *s);
 int launch_density_fast(Solver *s);
 int launch_force_fast(Solver *s);
+int launch_fused_probe(Solver *s, int mode);  // measurement only (fsa_sph_fast.hip)
 int launch_density_rigid_tuned(Solver *s);
 int launch_force_tuned(Solver *s);
 int debug_time_pass(Solver *s, int which, int ablate, int reps);

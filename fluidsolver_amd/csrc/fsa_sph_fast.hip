@@ -97,8 +97,24 @@ __device__ __forceinline__ float4 wall_sum(const DevParams<float> &P, int i, con
 // density + pressure + hit record (scenes without TYPE_RIGID particles: only fluid neighbours count)
 // ------------------------------------------------------------------------------------------------
 // EVAL = false: only the record (for a force pass that is not preceded by this solver's density pass).
+// the pass's LDS, in one piece so that another pass's can share the bytes (the fused probe at the end of the file)
+template <int BS, int ROWCAP, int Q, bool EVAL> struct DensityLds {
+    static constexpr int kWallWords = row_regs<BS, ROWCAP>() * BS / 32 + 1;
+    RowShared<BS, ROWCAP, false> sh;
+    Segments sg;
+    int wallSeg[kMaxSegs];  // does the segment hold a TYPE_BOUNDARY particle?
+    // which entries of a tile are TYPE_BOUNDARY particles, one bit each (entry 32 w + b at bit b of word w)
+    unsigned wallBits[2][kWallWords];
+    float queue[EVAL ? Q * BS : 1];
+};
+
+// `vb`: the workgroup's index in a grid of this pass alone (blockIdx.x when it is launched on its own)
 template <int BS, int ROWCAP, int Q, bool EVAL>
-__global__ __launch_bounds__(BS, kDensityBlocks) void density_record_kernel(DevParams<float> P, int n,
+__device__ __forceinline__ void density_record_body(RowShared<BS, ROWCAP, false> &sh, Segments &sg,
+                                                            int (&wallSeg)[kMaxSegs],
+                                                            unsigned (&wallBits)[2][DensityLds<BS, ROWCAP, Q, EVAL>::kWallWords],
+                                                            float *const queue, const int vb,
+                                                            const DevParams<float> P, int n,
                                                             const float4 *__restrict__ posType,
                                                             const float4 *__restrict__ velMass,
                                                             const float *__restrict__ restDensity,
@@ -113,13 +129,6 @@ __global__ __launch_bounds__(BS, kDensityBlocks) void density_record_kernel(DevP
                                                             float *__restrict__ pressure,
                                                             float2 *__restrict__ pd, int run_log) {
     using Shared = RowShared<BS, ROWCAP, false>;
-    __shared__ Shared sh;
-    __shared__ Segments sg;
-    __shared__ int wallSeg[kMaxSegs];  // does the segment hold a TYPE_BOUNDARY particle?
-    // which entries of a tile are TYPE_BOUNDARY particles, one bit each (entry 32 w + b at bit b of word w)
-    constexpr int kWallWords = row_regs<BS, ROWCAP>() * BS / 32 + 1;
-    __shared__ unsigned wallBits[2][kWallWords];
-    __shared__ float queue[EVAL ? Q * BS : 1];
     const int tid = threadIdx.x;
 #ifdef FSA_ABLATE
     const int dbg = run_log >> 8;  // experiment switches of a measurement build (results are then wrong)
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(BS, kDensityBlocks) void density_record_kernel(DevP
 #endif
     run_log &= 255;
     n = live_count(P, n);
-    const int blk = xcd_block(run_log);
+    const int blk = xcd_block_of(vb, run_log);
     const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
@@ -443,6 +452,31 @@ __global__ __launch_bounds__(BS, kDensityBlocks) void density_record_kernel(DevP
     }
 }
 
+template <int BS, int ROWCAP, int Q, bool EVAL>
+__global__ __launch_bounds__(BS, kDensityBlocks) void density_record_kernel(DevParams<float> P, int n,
+                                                            const float4 *__restrict__ posType,
+                                                            const float4 *__restrict__ velMass,
+                                                            const float *__restrict__ restDensity,
+                                                            const int *__restrict__ cellStart,
+                                                            const int *__restrict__ sortedHash,
+                                                            uint2 *__restrict__ hitWords,
+                                                            unsigned char *__restrict__ hitCount,
+                                                            unsigned char *__restrict__ wallCount,
+                                                            int *__restrict__ wallList,
+                                                            float4 *__restrict__ wallForce,
+                                                            float *__restrict__ density,
+                                                            float *__restrict__ pressure,
+                                                            float2 *__restrict__ pd, int run_log) {
+    __shared__ RowShared<BS, ROWCAP, false> sh;
+    __shared__ Segments sg;
+    __shared__ int wallSeg[kMaxSegs];
+    __shared__ unsigned wallBits[2][DensityLds<BS, ROWCAP, Q, EVAL>::kWallWords];
+    __shared__ float queue[EVAL ? Q * BS : 1];
+    density_record_body<BS, ROWCAP, Q, EVAL>(sh, sg, wallSeg, wallBits, queue, (int)blockIdx.x, P, n, posType, velMass, restDensity, cellStart, sortedHash,
+                                             hitWords, hitCount, wallCount, wallList, wallForce, density, pressure, pd,
+                                             run_log);
+}
+
 // ------------------------------------------------------------------------------------------------
 // wall pass: the TYPE_BOUNDARY neighbours of the listed particles, one particle per lane
 // ------------------------------------------------------------------------------------------------
@@ -480,8 +514,14 @@ template <int ROWCAP> struct PairTile {
 // `quorum` lanes have bits left -- those carry them over into the next segment's loop.  That keeps most lanes
 // busy in every trip although a lane's hits per row vary a lot (on a lattice half the lanes have no neighbour at
 // all in a given row).
+template <int ROWCAP> struct ForceLds {
+    RowShared<1, 4, false> sh;  // only its row table is used here
+    Segments sg;
+    PairTile<ROWCAP> tile;
+};
+
 template <int BS, int ROWCAP>
-__global__ __launch_bounds__(BS, kForceBlocks) void force_rows_kernel(DevParams<float> P, int n,
+__device__ __forceinline__ void force_rows_body(ForceLds<ROWCAP> &lds, const int vb, const DevParams<float> P, int n,
                                                         const float4 *__restrict__ posType,
                                                         const float4 *__restrict__ velMass,
                                                         const float2 *__restrict__ pd,
@@ -493,10 +533,10 @@ __global__ __launch_bounds__(BS, kForceBlocks) void force_rows_kernel(DevParams<
                                                         const float4 *__restrict__ wallForce,
                                                         int *__restrict__ wallList,
                                                         Vec3<float> *__restrict__ force, int run_log, int zone) {
-    using Shared = RowShared<1, 4, false>;  // only its row table is used here
-    __shared__ Shared sh;
-    __shared__ Segments sg;
-    __shared__ PairTile<ROWCAP> tile;
+    using Shared = RowShared<1, 4, false>;
+    Shared &sh = lds.sh;
+    Segments &sg = lds.sg;
+    PairTile<ROWCAP> &tile = lds.tile;
     const int tid = threadIdx.x;
 #ifdef FSA_ABLATE
     const int dbg = run_log >> 8;  // experiment switches of a measurement build (results are then wrong)
@@ -506,9 +546,9 @@ __global__ __launch_bounds__(BS, kForceBlocks) void force_rows_kernel(DevParams<
     run_log &= 255;
     const int quorum = (dbg >> 4) ? (dbg >> 4) : 40;
     // the wall pass has run: its list starts empty at the next density pass (Solver::wall_list_clean)
-    if (blockIdx.x == 0 && threadIdx.x == 0) wallList[0] = 0;
+    if (wallList && vb == 0 && threadIdx.x == 0) wallList[0] = 0;
     n = live_count(P, n);
-    const int blk = xcd_block(run_log);
+    const int blk = xcd_block_of(vb, run_log);
     const int b0 = blk * BS;
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
@@ -706,6 +746,69 @@ __global__ __launch_bounds__(BS, kForceBlocks) void force_rows_kernel(DevParams<
     }
 }
 
+template <int BS, int ROWCAP>
+__global__ __launch_bounds__(BS, kForceBlocks) void force_rows_kernel(DevParams<float> P, int n,
+                                                        const float4 *__restrict__ posType,
+                                                        const float4 *__restrict__ velMass,
+                                                        const float2 *__restrict__ pd,
+                                                        const int *__restrict__ cellStart,
+                                                        const int *__restrict__ sortedHash,
+                                                        const uint2 *__restrict__ hitWords,
+                                                        const unsigned char *__restrict__ hitCount,
+                                                        const unsigned char *__restrict__ wallCount,
+                                                        const float4 *__restrict__ wallForce,
+                                                        int *__restrict__ wallList,
+                                                        Vec3<float> *__restrict__ force, int run_log, int zone) {
+    __shared__ ForceLds<ROWCAP> lds;
+    force_rows_body<BS, ROWCAP>(lds, (int)blockIdx.x, P, n, posType, velMass, pd, cellStart, sortedHash, hitWords, hitCount,
+                                wallCount, wallForce, wallList, force, run_log, zone);
+}
+
+#ifdef FSA_ABLATE
+// ------------------------------------------------------------------------------------------------
+// measurement only: both passes in one launch, every other workgroup of an XCD a density workgroup
+// ------------------------------------------------------------------------------------------------
+struct FusedProbeArgs {
+    const float4 *posType, *velMass;
+    const float *restDensity;
+    const int *cellStart, *sortedHash;
+    uint2 *hitWords;
+    unsigned char *hitCount, *wallCount;
+    int *wallList;
+    float4 *wallForce;
+    float *density, *pressure;
+    float2 *pd;
+    Vec3<float> *force;
+};
+
+template <int BS, int ROWCAP, int Q>
+__global__ __launch_bounds__(BS, kForceBlocks) void fused_probe_kernel(DevParams<float> P, int n, FusedProbeArgs A, int run_log,
+                                                                     int mode) {
+    __shared__ union Lds {
+        DensityLds<BS, ROWCAP, Q, true> d;
+        ForceLds<ROWCAP> f;
+    } lds;
+    // on every XCD `stride` density workgroups, then `stride` force workgroups, and so on (mode >> 4; consecutive
+    // workgroups of an XCD go to different CUs in turn, so the stride decides which CUs see which kind)
+    const int stride = max(mode >> 4, 1);
+    mode &= 15;
+    const int xcd = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+    const int g = k / (2 * stride), r = k % (2 * stride);
+    const int vb = (g * stride + r % stride) * kXcds + xcd;
+    const bool first = r < stride;
+    const bool dens = mode == 0 ? first : mode == 1;  // mode 1 / 2: only density / only force workgroups do work
+    if (mode != 0 && !first) return;
+    if (dens)
+        density_record_body<BS, ROWCAP, Q, true>(lds.d.sh, lds.d.sg, lds.d.wallSeg, lds.d.wallBits, lds.d.queue, vb, P, n, A.posType, A.velMass, A.restDensity, A.cellStart,
+                                                 A.sortedHash, A.hitWords, A.hitCount, A.wallCount, A.wallList, A.wallForce,
+                                                 A.density, A.pressure, A.pd, run_log);
+    else
+        force_rows_body<BS, ROWCAP>(lds.f, vb, P, n, A.posType, A.velMass, A.pd, A.cellStart, A.sortedHash, A.hitWords,
+                                    A.hitCount, A.wallCount, A.wallForce, nullptr, A.force, run_log, 0);
+}
+
+#endif  // FSA_ABLATE
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -774,5 +877,41 @@ int launch_force_fast(Solver *s) {
     s->wall_list_clean = true;
     return FSA_OK;
 }
+
+#ifdef FSA_ABLATE
+// Timing probe: the density pass and the force replay of the present (sorted, recorded) state in ONE launch, their
+// workgroups alternating on every XCD so that each CU holds some of both.  mode 1 / 2: the same grid with only the
+// density / only the force workgroups working.  Results are those of the separate passes (both read what the other
+// writes, but the values written are the ones already there).
+int launch_fused_probe(Solver *s, int mode) {
+    if (s->precision != FSA_PRECISION_F32 || s->variant != 3 || !s->hits_valid || !s->pd_valid || s->slab)
+        return fail(FSA_ERR_INVALID, "the fused probe needs an fp32 variant-3 solver after a density and a force pass");
+    const int c = s->cur;
+    FusedProbeArgs A;
+    A.posType = (const float4 *)s->b.posType[c];
+    A.velMass = (const float4 *)s->b.velMass[c];
+    A.restDensity = (const float *)s->b.restDensity[c];
+    A.cellStart = s->b.cellStart;
+    A.sortedHash = s->b.sortedHash;
+    A.hitWords = (uint2 *)s->b.hitWords;
+    A.hitCount = s->b.hitCount;
+    A.wallCount = s->b.wallCount;
+    A.wallList = nullptr;  // wall neighbours in the density workgroups' tail
+    A.wallForce = (float4 *)s->b.wallForce;
+    A.density = (float *)s->b.density;
+    A.pressure = (float *)s->b.pressure;
+    A.pd = (float2 *)s->b.pd;
+    A.force = (Vec3<float> *)s->b.force;
+    hipLaunchKernelGGL((fused_probe_kernel<kTunedBS, kRowCap, kQueueD>), dim3(2 * tiled_grid(s, s->xcd_run_log)), dim3(kTunedBS),
+                       0, s->stream, s->pf, s->grid_n(), A, s->xcd_run_log, mode);
+    FSA_HIP(hipGetLastError());
+    return FSA_OK;
+}
+
+#else
+int launch_fused_probe(Solver *, int) {
+    return fail(FSA_ERR_INVALID, "the fused probe is part of measurement builds only (-DFSA_ABLATE)");
+}
+#endif
 
 }  // namespace fsa

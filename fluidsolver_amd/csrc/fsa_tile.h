@@ -395,9 +395,10 @@ __device__ __forceinline__ void group_d2(const float4 &X, const float4 &Y, const
 // 64 consecutive blocks go to one XCD instead of every eighth block (measured: 5 % on the force pass;
 // one contiguous eighth of the range per XCD is slower, the eighths differ too much in cost).
 constexpr int kXcds = 8;
-__device__ __forceinline__ int xcd_block(int run_log) {
-    const int x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+__device__ __forceinline__ int xcd_block_of(int b, int run_log) {  // b: the workgroup's index in the grid
+    const int x = b % kXcds, k = b / kXcds;
     return ((k >> run_log) * kXcds + x) * (1 << run_log) + (k & ((1 << run_log) - 1));
 }
+__device__ __forceinline__ int xcd_block(int run_log) { return xcd_block_of((int)blockIdx.x, run_log); }
 
 }  // namespace fsa
