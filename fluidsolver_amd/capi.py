@@ -53,7 +53,7 @@ EXPORTS = (
     "fsa_grid_team_set_field", "fsa_grid_team_set_particles", "fsa_grid_team_get_particles", "fsa_grid_team_advect",
     "fsa_grid_team_advect_particles", "fsa_grid_team_body_force", "fsa_grid_team_make_rhs",
     "fsa_grid_team_div_velocity", "fsa_grid_team_solve", "fsa_grid_team_update_u", "fsa_grid_team_step",
-    "fsa_grid_team_sync",
+    "fsa_grid_team_sync", "fsa_grid_team_create_hosted",
 )
 
 
@@ -208,6 +208,8 @@ def load() -> C.CDLL:
                                        C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
         "fsa_grid_team_create_rccl": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
+        "fsa_grid_team_create_hosted": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
         "fsa_grid_team_destroy": [H], "fsa_grid_team_get_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
         "fsa_grid_team_set_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
         "fsa_grid_team_set_particles": [H, C.c_int, C.c_void_p],
@@ -614,15 +616,56 @@ class GridSolver:
         return it.value, r.value
 
 
+class GridTransport(C.Structure):
+    """fsa_grid_transport"""
+    SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+    ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV), ("allreduce", ALLREDUCE)]
+
+
+def torch_grid_transport(group=None):
+    """an fsa_grid_transport over torch.distributed (any backend that moves CPU tensors: gloo)"""
+    import torch
+    import torch.distributed as dist
+
+    def view(ptr, nbytes, dtype=torch.uint8):
+        return torch.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype)
+
+    def sendrecv(_ctx, peer, send, send_bytes, recv, recv_bytes):
+        try:
+            reqs = [dist.isend(view(send, send_bytes), peer, group=group), dist.irecv(view(recv, recv_bytes), peer, group=group)]
+            for r in reqs:
+                r.wait()
+            return 0
+        except Exception as exc:  # noqa: BLE001  (an exception must not cross the C frames)
+            print(f"grid transport: {exc}", file=sys.stderr)
+            return 1
+
+    def allreduce(_ctx, buf, count, what):
+        try:
+            dt, size, op = ((torch.float64, 8, dist.ReduceOp.SUM), (torch.float32, 4, dist.ReduceOp.SUM),
+                            (torch.int32, 4, dist.ReduceOp.MAX))[what]
+            dist.all_reduce(view(buf, count * size, dt), op=op, group=group)
+            return 0
+        except Exception as exc:  # noqa: BLE001
+            print(f"grid transport: {exc}", file=sys.stderr)
+            return 1
+
+    tr = GridTransport(None, GridTransport.SENDRECV(sendrecv), GridTransport.ALLREDUCE(allreduce))
+    return tr
+
+
 class GridTeam:
     """fsa_grid_team: the grid solver on z-slabs.  Fields go in and out in the single solver's layout (the whole
-    grid).  GridTeam(dim, cuts, ...) holds all slabs in this process; GridTeam.rccl(...) holds slab `rank`."""
+    grid).  GridTeam(dim, cuts, ...) holds all slabs in this process; GridTeam.rccl(...) holds slab `rank`, and so
+    does GridTeam.hosted(...) with a caller-supplied transport (torch_grid_transport)."""
 
     FACE, CELL = GridSolver.FACE, GridSolver.CELL
 
     def __init__(self, dim, cuts, reach=1, padding=1, h=0.02, dt=0.001, rho=1.0, precision=PRECISION_F32, device: int = 0,
-                 rank=None, uid: bytes = None):
+                 rank=None, uid: bytes = None, transport=None):
         self.lib = load()
+        self._transport = transport  # (the callbacks must outlive the team)
         self.precision = precision
         self.dtype = np.float32 if precision == PRECISION_F32 else np.float64
         self.dim = tuple(int(d) for d in dim)
@@ -634,6 +677,10 @@ class GridTeam:
         if rank is None:
             check(self.lib.fsa_grid_team_create_local(cdim, self.padding, float(h), float(dt), float(rho), precision,
                                                       device, world, ccuts, int(reach), C.byref(h_)))
+        elif transport is not None:
+            check(self.lib.fsa_grid_team_create_hosted(cdim, self.padding, float(h), float(dt), float(rho), precision,
+                                                       device, int(rank), world, C.addressof(transport), ccuts, int(reach),
+                                                       C.byref(h_)))
         else:
             check(self.lib.fsa_grid_team_create_rccl(cdim, self.padding, float(h), float(dt), float(rho), precision,
                                                      device, int(rank), world, uid, ccuts, int(reach), C.byref(h_)))
@@ -646,6 +693,10 @@ class GridTeam:
     @classmethod
     def rccl(cls, dim, cuts, rank, uid, **kw):
         return cls(dim, cuts, rank=rank, uid=uid, **kw)
+
+    @classmethod
+    def hosted(cls, dim, cuts, rank, transport, **kw):
+        return cls(dim, cuts, rank=rank, transport=transport, **kw)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -218,7 +218,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void grid_advect_particles_kernel(GridDev<T> G, int n, const T *__restrict__ u,
                                                                        const T *__restrict__ v,
                                                                        const T *__restrict__ w, const T *src, T *pos,
-                                                                       T *color) {
+                                                                       const T *csrc, T *color) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     T x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1], z = src[3 * (size_t)i + 2];
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void grid_advect_particles_kernel(GridDev<T
     color[4 * (size_t)i] = (T)((double)g_abs(vx) / 0.01);
     color[4 * (size_t)i + 1] = 0;
     color[4 * (size_t)i + 2] = g_abs(vz) / l;
+    if (G.err) color[4 * (size_t)i + 3] = csrc[4 * (size_t)i + 3];  // (a slab writes into another array)
 }
 
 // bodyForce :579-588
@@ -841,7 +842,7 @@ static int grid_advect(GridSolver *g) {
 static int grid_advect_particles(GridSolver *g) {
     if (g->n_particles == 0) return FSA_OK;
     GRID_LAUNCH(grid_advect_particles_kernel<T>, gblocks(g->n_particles), G, g->n_particles, (const T *)g->u,
-                (const T *)g->v, (const T *)g->w, (const T *)g->ppos, (T *)g->ppos, (T *)g->pcolor);
+                (const T *)g->v, (const T *)g->w, (const T *)g->ppos, (T *)g->ppos, (const T *)g->pcolor, (T *)g->pcolor);
     return FSA_OK;
 }
 
@@ -1053,11 +1054,17 @@ static void *grid_field(GridSolver *g, const std::string &k, size_t *count) {
 //     solve, one plane of q before every stencil in between;
 //   * sums over all slabs for the two dot products and the residual of every round and for the divergence sum.
 // LOCAL teams hold all slabs in this process on one GPU and one stream (a rehearsal, and the reference for the
-// other kind): refreshes are device copies.  RCCL teams hold one slab per process: refreshes are ncclSend /
+// other kinds): refreshes are device copies.  RCCL teams hold one slab per process: refreshes are ncclSend /
 // ncclRecv pairs with the z-neighbours, the sums an ncclAllReduce of two doubles, all queued on the stream; the
-// loop state is the same on every rank, so every rank queues the same rounds.
+// loop state is the same on every rank, so every rank queues the same rounds.  HOSTED teams are RCCL teams whose
+// bytes travel through functions the caller supplies (fsa_grid_transport: MPI, sockets, torch.distributed ...):
+// every exchange is staged through pinned host memory and waits for the stream, which is slow and meant for hosts
+// without RCCL between their processes -- and it lets several processes share one GPU, which RCCL refuses.
 struct GridTeam {
-    int kind = 0;  // 0 LOCAL, 1 RCCL
+    int kind = 0;  // 0 LOCAL, 1 RCCL, 2 HOSTED
+    fsa_grid_transport via{};      // HOSTED
+    char *stage = nullptr;         // HOSTED: pinned host memory, send runs then receive runs
+    size_t stage_bytes = 0;
     int world = 1, rank = 0;
     int dim[3] = {0, 0, 0}, pad = 1, padz = 2, precision = FSA_PRECISION_F32, device = 0;
     std::vector<int> cuts;
@@ -1082,6 +1089,7 @@ static void team_free(GridTeam *t) {
         delete g;
     }
     if (t->comm) (void)ncclCommDestroy(t->comm);
+    if (t->stage) (void)hipHostFree(t->stage);
     void *ptrs[] = {t->err, t->sums, t->ppos, t->pcolor, t->pnew, t->pcnew};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1151,7 +1159,52 @@ static HaloRuns halo_runs(const GridTeam *t, GridSolver *g, bool faces, int f) {
     return h;
 }
 
+static int team_stage(GridTeam *t, size_t bytes) {
+    if (bytes <= t->stage_bytes) return FSA_OK;
+    if (t->stage) (void)hipHostFree(t->stage);
+    t->stage = nullptr;
+    t->stage_bytes = 0;
+    FSA_HIP(hipHostMalloc((void **)&t->stage, bytes, hipHostMallocDefault));
+    t->stage_bytes = bytes;
+    return FSA_OK;
+}
+
+// HOSTED: an element-wise sum (kind 0 doubles, 1 floats) or maximum (2 ints) of a device array over all ranks
+static int team_hosted_allreduce(GridTeam *t, void *dev, size_t count, int what) {
+    const size_t bytes = count * (what == 0 ? sizeof(double) : 4);
+    int rc = team_stage(t, bytes);
+    if (rc) return rc;
+    FSA_HIP(hipMemcpyAsync(t->stage, dev, bytes, hipMemcpyDeviceToHost, t->stream));
+    FSA_HIP(counted_stream_sync(t->stream));
+    if (t->via.allreduce(t->via.ctx, t->stage, count, what) != 0)
+        return fail(FSA_ERR_HIP, "grid team: the caller's allreduce failed");
+    FSA_HIP(hipMemcpyAsync(dev, t->stage, bytes, hipMemcpyHostToDevice, t->stream));
+    FSA_HIP(counted_stream_sync(t->stream));  // (the staging memory is used again by the next exchange)
+    return FSA_OK;
+}
+
 static int team_refresh(GridTeam *t, bool faces, int f) {
+    if (t->kind == 2) {
+        const HaloRuns h = halo_runs(t, t->m[0], faces, f);
+        if (!h.send[0] && !h.send[1]) return FSA_OK;
+        const size_t need = h.send_bytes[0] + h.send_bytes[1] + h.recv_bytes[0] + h.recv_bytes[1];
+        int rc = team_stage(t, need);
+        if (rc) return rc;
+        char *out[2] = {t->stage, t->stage + h.send_bytes[0]};
+        char *in[2] = {out[1] + h.send_bytes[1], out[1] + h.send_bytes[1] + h.recv_bytes[0]};
+        for (int d = 0; d < 2; d++)
+            if (h.send[d]) FSA_HIP(hipMemcpyAsync(out[d], h.send[d], h.send_bytes[d], hipMemcpyDeviceToHost, t->stream));
+        FSA_HIP(counted_stream_sync(t->stream));
+        // the slab below first on every rank: rank r's call meets rank r - 1's second one, no two wait for each other
+        for (int d = 0; d < 2; d++)
+            if (h.send[d] &&
+                t->via.sendrecv(t->via.ctx, t->rank + (d == 0 ? -1 : 1), out[d], h.send_bytes[d], in[d], h.recv_bytes[d]) != 0)
+                return fail(FSA_ERR_HIP, "grid team: the caller's sendrecv failed");
+        for (int d = 0; d < 2; d++)
+            if (h.send[d]) FSA_HIP(hipMemcpyAsync(h.recv[d], in[d], h.recv_bytes[d], hipMemcpyHostToDevice, t->stream));
+        FSA_HIP(counted_stream_sync(t->stream));
+        return FSA_OK;
+    }
     if (t->kind == 0) {
         for (size_t i = 0; i + 1 < t->m.size(); i++) {
             const HaloRuns lo = halo_runs(t, t->m[i], faces, f), hi = halo_runs(t, t->m[i + 1], faces, f);
@@ -1198,6 +1251,7 @@ static int team_sums(GridTeam *t, int offset, bool two, const std::vector<int> &
     hipLaunchKernelGGL(team_sum_kernel, dim3(1), dim3(kBlock), 0, t->stream, tp, offset, two ? 1 : 0, t->sums);
     FSA_HIP(hipGetLastError());
     if (t->kind == 1) TEAM_NCCL(ncclAllReduce(t->sums, t->sums, 2, ncclDouble, ncclSum, t->comm, t->stream));
+    if (t->kind == 2) return team_hosted_allreduce(t, t->sums, 2, 0);
     return FSA_OK;
 }
 
@@ -1233,11 +1287,17 @@ static int team_advect_particles(GridTeam *t) {
     }
     for (GridSolver *g : t->m)
         GRID_LAUNCH(grid_advect_particles_kernel<T>, gblocks(t->n_particles), G, t->n_particles, (const T *)g->u,
-                    (const T *)g->v, (const T *)g->w, (const T *)t->ppos, (T *)t->pnew, (T *)t->pcnew);
+                    (const T *)g->v, (const T *)g->w, (const T *)t->ppos, (T *)t->pnew, (const T *)t->pcolor, (T *)t->pcnew);
     if (t->kind == 1) {
         const ncclDataType_t dt = t->precision == FSA_PRECISION_F64 ? ncclDouble : ncclFloat;
         TEAM_NCCL(ncclAllReduce(t->pnew, t->pnew, n * 3, dt, ncclSum, t->comm, t->stream));
         TEAM_NCCL(ncclAllReduce(t->pcnew, t->pcnew, n * 4, dt, ncclSum, t->comm, t->stream));
+    }
+    if (t->kind == 2) {
+        const int what = t->precision == FSA_PRECISION_F64 ? 0 : 1;
+        int rc = team_hosted_allreduce(t, t->pnew, n * 3, what);
+        if (!rc) rc = team_hosted_allreduce(t, t->pcnew, n * 4, what);
+        if (rc) return rc;
     }
     std::swap(t->ppos, t->pnew);
     std::swap(t->pcolor, t->pcnew);
@@ -1392,8 +1452,9 @@ static int team_make(const int dim[3], int padding, double h, double dt, double 
                      int rank, int world, const int *cuts, int reach, GridTeam **out) {
     int rc = grid_check_args(dim, padding, h, dt, rho, precision, device);
     if (rc) return rc;
-    if (world < 1 || world > kMaxTeam || !cuts || reach < 1 || rank < 0 || rank >= world)
-        return fail(FSA_ERR_INVALID, "grid team: 1 to %d slabs, a reach of at least one plane", kMaxTeam);
+    if (world < 1 || (kind == 0 && world > kMaxTeam) || !cuts || reach < 1 || rank < 0 || rank >= world)
+        return fail(FSA_ERR_INVALID, "grid team: at least one slab (at most %d in one process), a reach of at least one plane",
+                    kMaxTeam);
     const int padz = std::max(padding, reach + 1);
     if (cuts[0] != 0 || cuts[world] != dim[2]) return fail(FSA_ERR_INVALID, "grid team: the cuts must span the planes 0 .. %d", dim[2]);
     for (int r = 0; r < world; r++)
@@ -1417,7 +1478,7 @@ static int team_make(const int dim[3], int padding, double h, double dt, double 
         rc = fail(FSA_ERR_HIP, "hipStreamCreate failed");
     if (rc == FSA_OK) rc = galloc((void **)&t->err, 4 * sizeof(int));
     if (rc == FSA_OK) rc = galloc((void **)&t->sums, 2 * sizeof(double));
-    const int r0 = kind == 0 ? 0 : rank, r1 = kind == 0 ? world : rank + 1;
+    const int r0 = kind == 0 ? 0 : rank, r1 = kind == 0 ? world : rank + 1;  // (RCCL, HOSTED: this process's slab)
     for (int r = r0; r < r1 && rc == FSA_OK; r++) {
         GridSolver *g = nullptr;
         rc = grid_make(dim, padding, h, dt, rho, precision, device, cuts[r], cuts[r + 1] - cuts[r], padz, t->err, t->stream,
@@ -1708,6 +1769,20 @@ int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt
     return FSA_OK;
 }
 
+int fsa_grid_team_create_hosted(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                                int rank, int world, const fsa_grid_transport *via, const int *cuts, int reach,
+                                fsa_grid_team **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!via || !via->sendrecv || !via->allreduce) return fail(FSA_ERR_INVALID, "the transport needs both functions");
+    GridTeam *t = nullptr;
+    int rc = team_make(dim, padding, h, dt, rho, precision, device, 2, rank, world, cuts, reach, &t);
+    if (rc) return rc;
+    t->via = *via;
+    *out = reinterpret_cast<fsa_grid_team *>(t);
+    return FSA_OK;
+}
+
 int fsa_grid_team_destroy(fsa_grid_team *ht) {
     GridTeam *t = reinterpret_cast<GridTeam *>(ht);
     if (!t) return FSA_OK;
@@ -1840,6 +1915,9 @@ int fsa_grid_team_step(fsa_grid_team *ht, int nsteps, int maxiter) {
 int fsa_grid_team_sync(fsa_grid_team *ht, int *error_bits) {
     GridTeam *t = reinterpret_cast<GridTeam *>(ht);
     TNEED(t);
+    // (between processes every rank learns of any rank's error: all of them call this)
+    if (t->kind == 1) TEAM_NCCL(ncclAllReduce(t->err, t->err, 1, ncclInt, ncclMax, t->comm, t->stream));
+    if (t->kind == 2) GTRY(team_hosted_allreduce(t, t->err, 1, 2));
     FSA_HIP(counted_stream_sync(t->stream));
     int err = 0;
     FSA_HIP(hipMemcpy(&err, t->err, sizeof(int), hipMemcpyDeviceToHost));

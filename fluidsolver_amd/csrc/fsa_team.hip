@@ -316,6 +316,7 @@ static int team_step(Team &t) {
         if (a < 1e-6 || b < 1e-6) break;
         last = mean;
     }
+    if (t.rounds.size() >= 8192) t.rounds.erase(t.rounds.begin(), t.rounds.begin() + 4096);  // (only the latest are asked for)
     t.rounds.push_back(rounds);
     rc = team_each(t, fsa_iisph_update);
     if (!rc) rc = team_exchange(t);

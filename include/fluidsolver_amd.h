@@ -565,7 +565,7 @@ int fsa_grid_step(fsa_grid *g, int nsteps, int maxiter);
  * reports, and the state is then invalid), one plane of p and of the search direction q (refreshed before
  * every stencil of the conjugate-gradient loop).  The two dot products and the residual of a round and the
  * divergence sum are totals over all slabs, so every slab runs the same rounds.  Every slab needs at least
- * max(padding, reach + 1) + 1 planes; at most 16 slabs.
+ * max(padding, reach + 1) + 1 planes; at most 16 slabs in one process.
  *
  * fsa_grid_team_create_local: all slabs in this process, on one GPU and one stream (refreshes are device
  * copies); fsa_grid_team_create_rccl: this process holds slab `rank` of `world` (one process per GPU), refreshes
@@ -581,11 +581,26 @@ int fsa_grid_step(fsa_grid *g, int nsteps, int maxiter);
  * for fp64).  The other calls are the team's forms of the fsa_grid_* calls of the same name.
  */
 typedef struct fsa_grid_team fsa_grid_team;
+/* A caller-supplied way between the processes of a team, for hosts without RCCL between them (MPI, sockets ...) and
+ * for several processes on one GPU, which RCCL refuses.  Both functions work on HOST memory and return 0 when the
+ * data has arrived.  sendrecv: send `send_bytes` to rank `peer` and receive `recv_bytes` from it (every rank
+ * calls it for the slab below first, then for the slab above, with the matching sizes on the other side).
+ * allreduce: in place over all ranks; what = 0: sum of `count` doubles, 1: sum of floats, 2: maximum of ints. */
+typedef struct fsa_grid_transport {
+    void *ctx;
+    int (*sendrecv)(void *ctx, int peer, const void *send, size_t send_bytes, void *recv, size_t recv_bytes);
+    int (*allreduce)(void *ctx, void *buf, size_t count, int what);
+} fsa_grid_transport;
 int fsa_grid_team_create_local(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
                                int world, const int *cuts, int reach, fsa_grid_team **out);
 int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
                               int rank, int world, const char id[FSA_SLAB_GROUP_ID_BYTES], const int *cuts, int reach,
                               fsa_grid_team **out);
+/* as fsa_grid_team_create_rccl, the bytes travelling through `via` (copied): every exchange is staged through pinned
+ * host memory and waits for the stream */
+int fsa_grid_team_create_hosted(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
+                                int rank, int world, const fsa_grid_transport *via, const int *cuts, int reach,
+                                fsa_grid_team **out);
 int fsa_grid_team_destroy(fsa_grid_team *t);
 int fsa_grid_team_get_field(fsa_grid_team *t, const char *name, void *dst, size_t bytes); /* synchronises */
 int fsa_grid_team_set_field(fsa_grid_team *t, const char *name, const void *src, size_t bytes);
@@ -599,7 +614,8 @@ int fsa_grid_team_div_velocity(fsa_grid_team *t, double *div_u_sum);
 int fsa_grid_team_solve(fsa_grid_team *t, int maxiter, int *iterations, double *residual);
 int fsa_grid_team_update_u(fsa_grid_team *t);
 int fsa_grid_team_step(fsa_grid_team *t, int nsteps, int maxiter);
-/* waits for the team's stream; *error_bits (may be NULL): 1 = a sample needed a plane its slab does not hold */
+/* waits for the team's stream; *error_bits (may be NULL): 1 = a sample needed a plane its slab does not hold (between
+ * processes: on any rank; collective there, every rank calls it) */
 int fsa_grid_team_sync(fsa_grid_team *t, int *error_bits);
 
 #ifdef __cplusplus

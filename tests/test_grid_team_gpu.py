@@ -193,8 +193,77 @@ def test_one_rank_over_rccl_equals_the_single_solver():
     for k in ("u", "v", "w", "p"):
         assert np.array_equal(t.get(k), g.get(k)), k
     assert np.array_equal(t.get_particles()[0], g.get_particles()[0])
+    assert np.array_equal(t.get_particles()[1], g.get_particles()[1])
     assert t.sync() == 0
     t.close()
+    g.close()
+
+
+def _assemble(parts, name, cuts, pad, shape):
+    """the whole grid's field from what every rank wrote for the planes it owns"""
+    out = np.zeros(shape, parts[0][name].dtype)
+    world = len(cuts) - 1
+    face = name in ("u", "v", "w")
+    for r, part in enumerate(parts):
+        lo, hi = cuts[r], cuts[r + 1]
+        if face:
+            lo, hi = lo + pad, hi + pad
+            if r == 0:
+                lo = 0
+            if r == world - 1:
+                hi = shape[0]
+        out[lo:hi] = part[name][lo:hi]
+        rest = part[name].copy()
+        rest[lo:hi] = 0
+        assert not rest.any(), f"rank {r} wrote planes of {name} that it does not own"
+    return out
+
+
+@pytest.mark.parametrize("dim,cuts,prec", [((16, 12, 16), [0, 7, 16], "f32"), ((16, 12, 18), [0, 5, 11, 18], "f32"),
+                                           ((12, 6, 12), [0, 4, 8, 12], "f64")])
+def test_ranks_in_separate_processes_equal_the_single_solver(tmp_path, dim, cuts, prec):
+    """one process per slab, all on this GPU, the bytes between them through a caller-supplied transport
+    (torch.distributed over gloo): what RCCL teams do between GPUs, rank by rank -- first, inner and last slab,
+    sums over the ranks, the same loop decisions everywhere"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from grid_team_worker import initial_fields, tracers
+    world = len(cuts) - 1
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "grid_team_worker.py"), "--rank", str(r), "--world",
+                               str(world), "--port", str(port), "--out", str(tmp_path), "--dim", *map(str, dim), "--cuts",
+                               *map(str, cuts), "--prec", prec], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = [p.communicate(timeout=240)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+    parts = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(world)]
+    precision = capi.PRECISION_F32 if prec == "f32" else capi.PRECISION_F64
+    g = capi.GridSolver(dim, precision=precision)
+    for k, f in initial_fields(g.shape, g.dtype, 91, 0.3).items():
+        g.set(k, f)
+    g.set_particles(tracers(dim, 0.02, g.dtype, 92))
+    g.step(4, 2000)
+    it, res = g.solve(7)
+    for r in range(world):
+        assert int(parts[r]["bits"]) == 0
+        assert parts[r]["cg"][0] == it
+        # every rank holds all tracers
+        assert np.array_equal(parts[r]["pos"], parts[0]["pos"]) and np.array_equal(parts[r]["color"], parts[0]["color"])
+    for k in ("u", "v", "w", "p", "q", "divU"):
+        got, want = _assemble(parts, k, cuts, 1, g.shape(k)), g.get(k)
+        if prec == "f32":
+            assert np.array_equal(got, want), k
+        else:
+            assert rel_err(got, want) <= 1e-5, k
+    pos, col = g.get_particles()
+    if prec == "f32":
+        assert np.array_equal(parts[0]["pos"], pos) and np.array_equal(parts[0]["color"], col)
+        assert parts[0]["cg"][1] == res
     g.close()
 
 
