@@ -53,7 +53,7 @@ EXPORTS = (
     "fsa_grid_team_set_field", "fsa_grid_team_set_particles", "fsa_grid_team_get_particles", "fsa_grid_team_advect",
     "fsa_grid_team_advect_particles", "fsa_grid_team_body_force", "fsa_grid_team_make_rhs",
     "fsa_grid_team_div_velocity", "fsa_grid_team_solve", "fsa_grid_team_update_u", "fsa_grid_team_step",
-    "fsa_grid_team_sync", "fsa_grid_team_create_hosted",
+    "fsa_grid_team_sync", "fsa_grid_team_create_hosted", "fsa_slab_group_create_hosted",
 )
 
 
@@ -210,6 +210,8 @@ def load() -> C.CDLL:
                                       C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
         "fsa_grid_team_create_hosted": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
+        "fsa_slab_group_create_hosted": [H, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                         C.POINTER(C.c_void_p)],
         "fsa_grid_team_destroy": [H], "fsa_grid_team_get_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
         "fsa_grid_team_set_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
         "fsa_grid_team_set_particles": [H, C.c_int, C.c_void_p],
@@ -616,15 +618,15 @@ class GridSolver:
         return it.value, r.value
 
 
-class GridTransport(C.Structure):
-    """fsa_grid_transport"""
+class HostTransport(C.Structure):
+    """fsa_host_transport"""
     SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
     ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
     _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV), ("allreduce", ALLREDUCE)]
 
 
-def torch_grid_transport(group=None):
-    """an fsa_grid_transport over torch.distributed (any backend that moves CPU tensors: gloo)"""
+def torch_host_transport(group=None):
+    """an fsa_host_transport over torch.distributed (any backend that moves CPU tensors: gloo)"""
     import torch
     import torch.distributed as dist
 
@@ -638,7 +640,7 @@ def torch_grid_transport(group=None):
                 r.wait()
             return 0
         except Exception as exc:  # noqa: BLE001  (an exception must not cross the C frames)
-            print(f"grid transport: {exc}", file=sys.stderr)
+            print(f"host transport: {exc}", file=sys.stderr)
             return 1
 
     def allreduce(_ctx, buf, count, what):
@@ -648,11 +650,14 @@ def torch_grid_transport(group=None):
             dist.all_reduce(view(buf, count * size, dt), op=op, group=group)
             return 0
         except Exception as exc:  # noqa: BLE001
-            print(f"grid transport: {exc}", file=sys.stderr)
+            print(f"host transport: {exc}", file=sys.stderr)
             return 1
 
-    tr = GridTransport(None, GridTransport.SENDRECV(sendrecv), GridTransport.ALLREDUCE(allreduce))
+    tr = HostTransport(None, HostTransport.SENDRECV(sendrecv), HostTransport.ALLREDUCE(allreduce))
     return tr
+
+
+torch_grid_transport = torch_host_transport
 
 
 class GridTeam:
@@ -780,6 +785,16 @@ class SlabGroup:
         check(lib.fsa_slab_group_create_local(len(solvers), hs, (C.c_int * len(cuts))(*cuts), int(halo),
                                               int(record_cap), C.byref(h)))
         return cls(h, list(solvers))
+
+    @classmethod
+    def hosted(cls, solver, rank, world, transport, cuts, halo, record_cap):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.fsa_slab_group_create_hosted(solver._h, int(rank), int(world), C.addressof(transport),
+                                               (C.c_int * len(cuts))(*cuts), int(halo), int(record_cap), C.byref(h)))
+        g = cls(h, [solver])
+        g._transport = transport  # (the callbacks must outlive the group)
+        return g
 
     @classmethod
     def rccl(cls, solver, rank, world, uid: bytes, cuts, halo, record_cap):

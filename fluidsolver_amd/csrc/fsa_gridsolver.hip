@@ -1057,12 +1057,12 @@ static void *grid_field(GridSolver *g, const std::string &k, size_t *count) {
 // other kinds): refreshes are device copies.  RCCL teams hold one slab per process: refreshes are ncclSend /
 // ncclRecv pairs with the z-neighbours, the sums an ncclAllReduce of two doubles, all queued on the stream; the
 // loop state is the same on every rank, so every rank queues the same rounds.  HOSTED teams are RCCL teams whose
-// bytes travel through functions the caller supplies (fsa_grid_transport: MPI, sockets, torch.distributed ...):
+// bytes travel through functions the caller supplies (fsa_host_transport: MPI, sockets, torch.distributed ...):
 // every exchange is staged through pinned host memory and waits for the stream, which is slow and meant for hosts
 // without RCCL between their processes -- and it lets several processes share one GPU, which RCCL refuses.
 struct GridTeam {
     int kind = 0;  // 0 LOCAL, 1 RCCL, 2 HOSTED
-    fsa_grid_transport via{};      // HOSTED
+    fsa_host_transport via{};      // HOSTED
     char *stage = nullptr;         // HOSTED: pinned host memory, send runs then receive runs
     size_t stage_bytes = 0;
     int world = 1, rank = 0;
@@ -1770,7 +1770,7 @@ int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt
 }
 
 int fsa_grid_team_create_hosted(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
-                                int rank, int world, const fsa_grid_transport *via, const int *cuts, int reach,
+                                int rank, int world, const fsa_host_transport *via, const int *cuts, int reach,
                                 fsa_grid_team **out) {
     if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
     *out = nullptr;

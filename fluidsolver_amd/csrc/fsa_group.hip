@@ -65,7 +65,10 @@ struct Member {
 };
 
 struct Group {
-    int kind = 0;  // 0 LOCAL, 1 RCCL
+    int kind = 0;  // 0 LOCAL, 1 RCCL, 2 HOSTED (as RCCL, the bytes through the caller's functions and host memory)
+    fsa_host_transport via{};
+    char *stage = nullptr;  // HOSTED: pinned host memory for the messages of a step
+    size_t stage_bytes = 0;
     bool overlap = true;
     int world = 0, halo = 0, record_cap = 0, rb = 0, slack = 4096;
     std::vector<int> cuts;
@@ -298,6 +301,43 @@ static int transport(Group &g, long long msg) {
                                 peer.size_out[1 - d], size_in[d]);
             }
         }
+    } else if (g.kind == 2) {
+        Member &mb = g.m[0];
+        Solver *s = mb.s;
+        int size_in[2] = {0, 0};
+        int rc = incoming_sizes(g, mb, msg, size_in);
+        if (rc) return rc;
+        size_t out_bytes[2] = {0, 0}, in_bytes[2] = {0, 0}, need = 0;
+        for (int d = 0; d < 2; d++) {
+            if (!mb.send[d]) continue;
+            out_bytes[d] = (size_t)(1 + mb.size_out[d]) * g.rb;
+            in_bytes[d] = (size_t)(1 + size_in[d]) * g.rb;
+            need += out_bytes[d] + in_bytes[d];
+        }
+        if (need > g.stage_bytes) {
+            if (g.stage) (void)hipHostFree(g.stage);
+            g.stage = nullptr;
+            g.stage_bytes = 0;
+            FSA_HIP(hipHostMalloc((void **)&g.stage, need, hipHostMallocDefault));
+            g.stage_bytes = need;
+        }
+        char *out[2] = {g.stage, g.stage + out_bytes[0]};
+        char *in[2] = {out[1] + out_bytes[1], out[1] + out_bytes[1] + in_bytes[0]};
+        if (mb.comm != s->stream) FSA_HIP(hipStreamWaitEvent(mb.comm, mb.ev_pack[slot], 0));
+        for (int d = 0; d < 2; d++)
+            if (mb.send[d]) FSA_HIP(hipMemcpyAsync(out[d], mb.send[d], out_bytes[d], hipMemcpyDeviceToHost, mb.comm));
+        FSA_HIP(counted_stream_sync(mb.comm));
+        // the slab below first on every rank: rank r's call meets rank r - 1's second one
+        for (int d = 0; d < 2; d++)
+            if (mb.send[d] && g.via.sendrecv(g.via.ctx, mb.rank + (d == 0 ? -1 : 1), out[d], out_bytes[d], in[d], in_bytes[d]) != 0)
+                return fail(FSA_ERR_HIP, "slab group: the caller's sendrecv failed");
+        for (int d = 0; d < 2; d++) {
+            if (!mb.send[d]) continue;
+            FSA_HIP(hipMemcpyAsync(mb.recv[d], in[d], in_bytes[d], hipMemcpyHostToDevice, mb.comm));
+            mb.bound_in[d] = size_in[d];
+        }
+        FSA_HIP(counted_stream_sync(mb.comm));  // (the staging memory is used again by the next message)
+        FSA_HIP(hipEventRecord(mb.ev_arrived, mb.comm));
     } else {
         Member &mb = g.m[0];
         Solver *s = mb.s;
@@ -354,7 +394,7 @@ static int group_step(Group &g) {
     if (any && !all)
         return fail(FSA_ERR_INVALID, "the particles of a member of the slab group were changed between two steps of the "
                                      "group: destroy the group and make a new one");
-    if (g.kind == 1 && msg > 0 && !all)
+    if (g.kind != 0 && msg > 0 && !all)
         return fail(FSA_ERR_INVALID, "the particles of a member of the slab group were changed between two steps of the "
                                      "group (its messages are already with the neighbours): destroy the group and make a "
                                      "new one");
@@ -511,6 +551,38 @@ int fsa_slab_group_create_rccl(fsa_solver *solver, int rank, int world, const ch
     return FSA_OK;
 }
 
+int fsa_slab_group_create_hosted(fsa_solver *solver, int rank, int world, const fsa_host_transport *via, const int *cuts,
+                                 int halo, int record_cap, fsa_slab_group **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !solver || !cuts || !via || !via->sendrecv || halo < 1 || record_cap < 0)
+        return fail(FSA_ERR_INVALID, "bad argument");
+    for (int r = 0; r < world; r++)
+        if (cuts[r + 1] - cuts[r] < halo + 1)
+            return fail(FSA_ERR_INVALID, "slab %d has %d layers, fewer than halo + 1 = %d", r, cuts[r + 1] - cuts[r], halo + 1);
+    Group *g = new (std::nothrow) Group();
+    if (!g) return fail(FSA_ERR_NOMEM, "out of host memory");
+    g->kind = 2;
+    g->via = *via;
+    g->overlap = overlap_wanted();
+    g->slack = slack_wanted();
+    g->world = world;
+    g->halo = halo;
+    g->record_cap = record_cap;
+    g->cuts.assign(cuts, cuts + world + 1);
+    Solver *s = reinterpret_cast<Solver *>(solver);
+    g->rb = slab_record_bytes(s);
+    g->m.resize(1);
+    const int rc = setup_member(*g, g->m[0], s, rank);
+    if (rc) {
+        free_member(g->m[0]);
+        delete g;
+        return rc;
+    }
+    *out = reinterpret_cast<fsa_slab_group *>(g);
+    return FSA_OK;
+}
+
 int fsa_slab_group_step(fsa_slab_group *hg, int nsteps) {
     Group *g = reinterpret_cast<Group *>(hg);
     if (!g) return fail(FSA_ERR_INVALID, "group is NULL");
@@ -575,6 +647,7 @@ int fsa_slab_group_destroy(fsa_slab_group *hg) {
     if (!g) return FSA_OK;
     for (Member &mb : g->m) free_member(mb);
     if (g->comm) (void)ncclCommDestroy(g->comm);
+    if (g->stage) (void)hipHostFree(g->stage);
     delete g;
     return FSA_OK;
 }

@@ -942,8 +942,10 @@ def _bench_distributed(args, build_scene):
     rigid = torch.tensor([int((np.asarray(sc["type"]) == 4).any())])
     dist.all_reduce(rigid, op=dist.ReduceOp.MAX)  # the ranks hold different parts of the scene and must agree
     has_rigid = bool(rigid.item())
-    native = use_nccl and os.environ.get("FSA_SLAB_NATIVE", "1") != "0" and not has_rigid and \
-        (args.variant is None or args.variant == 3)
+    # (ranks that share a card, or FSA_SLAB_BACKEND=gloo: the same group of the library with its messages staged through
+    # the host and this job's gloo group: one host wait per message, for rehearsals; FSA_SLAB_NATIVE=0: the Python driver)
+    native = os.environ.get("FSA_SLAB_NATIVE", "1") != "0" and not has_rigid and (args.variant is None or args.variant == 3)
+    hosted = native and not use_nccl
     ss = SlabSolver(sc, rank, world, transport,
                     lambda P, held, cap: HipSlabBackend(P, held, cap, device_index, args.variant),
                     exchange_buffers=not native, cuts=cuts0, layer_hist=layer_hist, has_rigid=has_rigid)
@@ -952,6 +954,9 @@ def _bench_distributed(args, build_scene):
     from . import capi
 
     def make_group():
+        if hosted:
+            return capi.SlabGroup.hosted(ss.backend.solver, rank, world, capi.torch_host_transport(), ss.layout.cuts, ss.halo,
+                                         ss.record_cap)
         uid = [None]
         if rank == 0:
             try:
@@ -1067,7 +1072,8 @@ def _bench_distributed(args, build_scene):
                slab_cuts=ss.layout.cuts, halo_layers=ss.layout.halo, max_local_particles=int(mx[1]),
                mean_local_particles=float(sm[1]) / world, sum_local_particles=int(sm[1]), lost_particles=int(sm[2]),
                records_sent_per_step=float(sm[4]) / max(args.steps, 1), comm_backend=backend,
-               slab_step="library slab group (RCCL send/recv, no host round trip)" if native else
+               slab_step=("library slab group, messages staged through the host over gloo (one host wait per message)"
+                          if hosted else "library slab group (RCCL send/recv, no host round trip)") if native else
                          "torch.distributed transport, two host round trips per step",
                exchange_ms_per_step_max=float(mx[5]), host_syncs_in_timed_steps=int(mx[6]),
                recuts=ss.recuts - recuts0, recut_every=recut_every)

@@ -488,9 +488,25 @@ typedef struct fsa_slab_group_stats {
 } fsa_slab_group_stats;
 int fsa_slab_group_create_local(int world, fsa_solver **solvers, const int *cuts /* world + 1 */, int halo,
                                 int record_cap, fsa_slab_group **out);
+/* A caller-supplied way between the processes of a slab group or a grid team, for hosts without RCCL between them
+ * (MPI, sockets ...) and
+ * for several processes on one GPU, which RCCL refuses.  Both functions work on HOST memory and return 0 when the
+ * data has arrived.  sendrecv: send `send_bytes` to rank `peer` and receive `recv_bytes` from it (every rank
+ * calls it for the slab below first, then for the slab above, with the matching sizes on the other side).
+ * allreduce: in place over all ranks; what = 0: sum of `count` doubles, 1: sum of floats, 2: maximum of ints. */
+typedef struct fsa_host_transport {
+    void *ctx;
+    int (*sendrecv)(void *ctx, int peer, const void *send, size_t send_bytes, void *recv, size_t recv_bytes);
+    int (*allreduce)(void *ctx, void *buf, size_t count, int what);
+} fsa_host_transport;
 int fsa_slab_group_unique_id(char id[FSA_SLAB_GROUP_ID_BYTES]);
 int fsa_slab_group_create_rccl(fsa_solver *solver, int rank, int world, const char id[FSA_SLAB_GROUP_ID_BYTES],
                                const int *cuts /* world + 1 */, int halo, int record_cap, fsa_slab_group **out);
+/* as fsa_slab_group_create_rccl, the records travelling through the caller's transport: every step waits for its
+ * messages on the host (the one-slab-per-process step for hosts without RCCL between their processes, and for
+ * several processes on one GPU) */
+int fsa_slab_group_create_hosted(fsa_solver *solver, int rank, int world, const fsa_host_transport *via, const int *cuts,
+                                 int halo, int record_cap, fsa_slab_group **out);
 /* Queues nsteps steps; returns without waiting for them. */
 int fsa_slab_group_step(fsa_slab_group *g, int nsteps);
 /* Waits for everything queued, brings the member solvers' host-side counts up to date, fills *st (may be NULL). */
@@ -581,16 +597,6 @@ int fsa_grid_step(fsa_grid *g, int nsteps, int maxiter);
  * for fp64).  The other calls are the team's forms of the fsa_grid_* calls of the same name.
  */
 typedef struct fsa_grid_team fsa_grid_team;
-/* A caller-supplied way between the processes of a team, for hosts without RCCL between them (MPI, sockets ...) and
- * for several processes on one GPU, which RCCL refuses.  Both functions work on HOST memory and return 0 when the
- * data has arrived.  sendrecv: send `send_bytes` to rank `peer` and receive `recv_bytes` from it (every rank
- * calls it for the slab below first, then for the slab above, with the matching sizes on the other side).
- * allreduce: in place over all ranks; what = 0: sum of `count` doubles, 1: sum of floats, 2: maximum of ints. */
-typedef struct fsa_grid_transport {
-    void *ctx;
-    int (*sendrecv)(void *ctx, int peer, const void *send, size_t send_bytes, void *recv, size_t recv_bytes);
-    int (*allreduce)(void *ctx, void *buf, size_t count, int what);
-} fsa_grid_transport;
 int fsa_grid_team_create_local(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
                                int world, const int *cuts, int reach, fsa_grid_team **out);
 int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
@@ -599,7 +605,7 @@ int fsa_grid_team_create_rccl(const int dim[3], int padding, double h, double dt
 /* as fsa_grid_team_create_rccl, the bytes travelling through `via` (copied): every exchange is staged through pinned
  * host memory and waits for the stream */
 int fsa_grid_team_create_hosted(const int dim[3], int padding, double h, double dt, double rho, int precision, int device,
-                                int rank, int world, const fsa_grid_transport *via, const int *cuts, int reach,
+                                int rank, int world, const fsa_host_transport *via, const int *cuts, int reach,
                                 fsa_grid_team **out);
 int fsa_grid_team_destroy(fsa_grid_team *t);
 int fsa_grid_team_get_field(fsa_grid_team *t, const char *name, void *dst, size_t bytes); /* synchronises */

@@ -47,7 +47,7 @@ def main():
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world)
     precision = capi.PRECISION_F32 if a.prec == "f32" else capi.PRECISION_F64
-    tr = capi.torch_grid_transport()
+    tr = capi.torch_host_transport()
     t = capi.GridTeam.hosted(a.dim, a.cuts, a.rank, tr, reach=a.reach, precision=precision)
     for k, f in initial_fields(t.shape, t.dtype, 91, a.scale).items():
         t.set(k, f)

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--recut-at", type=int, default=0, help="re-cut the slabs after this many steps")
     ap.add_argument("--mode", choices=["wcsph", "iisph"], default="wcsph")
+    ap.add_argument("--group", choices=["none", "hosted"], default="none",
+                    help="hosted: the library's one-slab-per-process group, its messages over this job's gloo group")
     a = ap.parse_args()
 
     import torch
@@ -141,6 +143,23 @@ def main():
         out.update(cuts=np.asarray(ss.layout.cuts), lost=np.asarray(ss.lost), sent=np.asarray(ss.sent_records),
                    rounds=np.asarray(team.rounds))
         np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **out)
+        ss.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if a.group == "hosted":
+        from fluidsolver_amd import capi
+        ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts, exchange_buffers=False)
+        g = capi.SlabGroup.hosted(ss.backend.solver, a.rank, a.world, capi.torch_host_transport(), ss.layout.cuts, ss.halo,
+                                  ss.record_cap)
+        g.step(7)
+        g.step(a.steps - 7)
+        st = g.sync()
+        out = ss.owned()
+        out.update(cuts=np.asarray(ss.layout.cuts), lost=np.asarray(int(st.lost)), sent=np.asarray(int(st.records_sent)),
+                   owned_count=np.asarray(len(out["uniqueId"])), error_bits=np.asarray(int(st.error_bits)))
+        np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **out)
+        g.close()
         ss.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -24,12 +24,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0, scene="dam", mode="wcsph"):
+def run_ranks(world, backend, steps, out, timeout=600, variant=2, recut_at=0, scene="dam", mode="wcsph", group="none"):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "--rank", str(r), "--world",
                                str(world), "--port", str(port), "--out", str(out), "--backend", backend, "--steps",
                                str(steps), "--variant", str(variant), "--recut-at", str(recut_at), "--scene", scene,
-                               "--mode", mode])
+                               "--mode", mode, "--group", group])
              for r in range(world)]
     try:
         codes = [p.wait(timeout=timeout) for p in procs]

@@ -65,6 +65,19 @@ def test_two_ranks_equal_plain_solver(tmp_path, orc32, variant):
     assert rel_err(got["pos"], orc_ref["pos"][ro], scale=1.0) < tol
 
 
+@pytest.mark.parametrize("world,scene", [(2, "dam"), (3, "ddam"), (3, "drift")])
+def test_library_group_with_one_process_per_slab_equals_plain_solver(tmp_path, world, scene):
+    """the library's one-slab-per-process group (what RCCL runs between GPUs: message sizes derived on both ends from
+    counts three steps old, pack / transport / unpack queued around the solver's step), every slab in a process of its
+    own on this GPU, the messages through a caller-supplied transport over gloo"""
+    from slab_worker import SCENES
+    parts = run_ranks(world, "hip", STEPS, tmp_path, variant=3, scene=scene, group="hosted")
+    assert sum(int(p["lost"]) for p in parts) == 0 and all(int(p["error_bits"]) == 0 for p in parts)
+    assert sum(int(p["sent"]) for p in parts) > 0
+    uid, got = merged(parts)
+    assert_same_bits(uid, got, plain_gpu_run(SCENES[scene](), STEPS, 3))
+
+
 def test_recut_two_ranks_equal_plain_solver(tmp_path):
     """lopsided cuts, re-cut after 10 of 25 steps through fsa_slab_export_owned: still the plain run's bits"""
     from slab_worker import test_scene
@@ -161,4 +174,4 @@ def test_bench_ends_non_zero_when_the_rccl_group_cannot_be_made(tmp_path):
     r, line = _bench_two_ranks_on_one_gpu("gloo", tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["config"]["comm_backend"] == "gloo"
-    assert "torch.distributed transport" in line["config"]["slab_step"]
+    assert "staged through the host" in line["config"]["slab_step"] and line["config"]["lost_particles"] == 0
