@@ -176,6 +176,59 @@ def run_single(args, jitter=None, keep_scene=False, variant=None, spinup=None, r
                 variant=3 if variant is None else variant)
 
 
+def next_rows(args):
+    """The steps beside the WCSPH one, each timed briefly on the GPU (not part of `value`): the DFSPH step and the
+    IISPH step at the bench scene's size, one step of the Eulerian grid solver at 256^3."""
+    from fluidsolver_amd import capi, scenes
+    out = {}
+    dims = {"dam16m": (256, 256, 256), "dam1m": (128, 64, 128), "dam128k": (64, 32, 64)}.get(args.scene)
+    if dims:
+        sc = scenes.dam_break(*dims)
+        s = capi.Solver(capi.make_params(capi.PRECISION_F32, **sc["params"]), len(sc["pos"]))
+        s.upload(sc)
+        s.setup_dfsph()
+        s.step_dfsph(3)
+        s.synchronize()
+        t0 = time.perf_counter()
+        s.step_dfsph(5)
+        s.synchronize()
+        out["dfsph"] = {"scene": f"dam break {dims[0]}x{dims[1]}x{dims[2]} (SolveDFSPH, two correction loops, stop tests on the device)",
+                        "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3, "particles": len(sc["pos"])}
+        s.close()
+        sc = scenes.dam_break(*dims, wall_type=scenes.TYPE_RIGID)
+        sc["mass"][sc["type"] == scenes.TYPE_RIGID] = scenes.rigid_mass(sc["params"]["spacing"], sc["params"]["restdensity"])
+        sc["group"][sc["type"] == scenes.TYPE_RIGID] = 1
+        sc["params"] = dict(sc["params"], viscosity=0.05, **scenes.IISPH_PARAMS)
+        s = capi.Solver(capi.make_params(capi.PRECISION_F32, **sc["params"]), len(sc["pos"]))
+        s.upload(sc)
+        s.setup_iisph()
+        s.step_iisph(3)
+        s.synchronize()
+        t0 = time.perf_counter()
+        s.step_iisph(5)
+        s.synchronize()
+        out["iisph"] = {"scene": f"dam break {dims[0]}x{dims[1]}x{dims[2]} in a tank of TYPE_RIGID particles (SolveIISPH, up to 10 "
+                                 "pressure rounds)",
+                        "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3, "particles": len(sc["pos"])}
+        s.close()
+    g = capi.GridSolver((256, 256, 256), padding=1, h=0.02, dt=0.001, rho=1.0)
+    rng = np.random.default_rng(1)
+    for k in ("u", "w"):
+        g.set(k, (0.2 * rng.standard_normal(g.shape(k))).astype(g.dtype))
+    g.step(1)
+    g.make_rhs()
+    g.synchronize()
+    t0 = time.perf_counter()
+    it, _ = g.solve(200)
+    g.synchronize()
+    ms_round = (time.perf_counter() - t0) * 1e3 / (it + 1)
+    out["grid"] = {"scene": "Eulerian grid solver, 256^3 cells, fp32: conjugate-gradient rounds of the pressure projection",
+                   "ms_per_cg_round": ms_round, "GB_per_s": 12 * 4 * 256 ** 3 / (ms_round * 1e-3) / 1e9,
+                   "bytes_per_cell_and_round": 48}
+    g.close()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -302,6 +355,8 @@ def main():
                 "kernel_variant": VARIANT_NAMES[1], "ms_per_step": ex["wall"] / steps * 1e3,
                 "value": ex["n_fluid"] * steps / ex["wall"], "unit": "particle-steps/s",
                 "kernels_ms": {k: (ms / c if c else 0.0) for k, (c, ms) in ex["kernels"].items()}}
+    if single and args.jitter == 0 and not os.environ.get("FSA_BENCH_NO_DEVELOPED") and not os.environ.get("FSA_BENCH_NO_NEXT"):
+        out["next_rows"] = next_rows(args)
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(res["scene"], args.scene)
     print(json.dumps(out))
