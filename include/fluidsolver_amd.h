@@ -210,9 +210,10 @@ int fsa_update_position(fsa_solver *s);
 int fsa_update_velocities(fsa_solver *s);
 /* correctDensityError / correctDivergenceError (solver/sph_solver.cu:144-256): Jacobi rounds until the
  * maximum of error[] drops below ethres or maxiter rounds are done, then updatePosition /
- * UpdateVelocities.  The maximum is reduced on the device (the reference copies error[] to the host
- * every round); one 4- or 8-byte read-back per round remains, so both synchronise.  *iterations = rounds
- * of applyPStiff done, *last_error = last maximum; either pointer may be NULL. */
+ * UpdateVelocities.  All rounds are queued at once; the maximum and the test against the threshold run on the
+ * device (the reference copies error[] to the host every round), and the passes of the rounds after the stop
+ * return at once.  *iterations = rounds of applyPStiff done, *last_error = last maximum; either pointer may be
+ * NULL, and only a call that asks for one of them waits for the device (one read-back). */
 int fsa_correct_density_error(fsa_solver *s, int maxiter, double ethres, int *iterations, double *last_error);
 int fsa_correct_divergence_error(fsa_solver *s, int maxiter, double ethres, int *iterations, double *last_error);
 /* SetupDFSPH after the scene is uploaded (solver/sph_solver.cpp:102-106): sort + computeDensityAlpha */
