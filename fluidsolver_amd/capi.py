@@ -53,7 +53,8 @@ EXPORTS = (
     "fsa_grid_team_set_field", "fsa_grid_team_set_particles", "fsa_grid_team_get_particles", "fsa_grid_team_advect",
     "fsa_grid_team_advect_particles", "fsa_grid_team_body_force", "fsa_grid_team_make_rhs",
     "fsa_grid_team_div_velocity", "fsa_grid_team_solve", "fsa_grid_team_update_u", "fsa_grid_team_step",
-    "fsa_grid_team_sync", "fsa_grid_team_create_hosted", "fsa_slab_group_create_hosted",
+    "fsa_grid_team_sync", "fsa_grid_team_create_hosted", "fsa_slab_group_create_hosted", "fsa_slab_enable_dfsph",
+    "fsa_slab_owned_max",
 )
 
 
@@ -210,6 +211,8 @@ def load() -> C.CDLL:
                                       C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
         "fsa_grid_team_create_hosted": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
+        "fsa_slab_enable_dfsph": [H],
+        "fsa_slab_owned_max": [H, C.c_char_p, C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_double)],
         "fsa_slab_group_create_hosted": [H, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)],
         "fsa_grid_team_destroy": [H], "fsa_grid_team_get_field": [H, C.c_char_p, C.c_void_p, C.c_size_t],
@@ -518,6 +521,13 @@ class Solver:
         v = C.c_double()
         check(self.lib.fsa_slab_owned_sum(self._h, name.encode(), (C.c_int * 2)(*own), C.byref(v)))
         return v.value
+
+    def slab_owned_max(self, name, own, start) -> float:
+        v = C.c_double()
+        check(self.lib.fsa_slab_owned_max(self._h, name.encode(), (C.c_int * 2)(*own), float(start), C.byref(v)))
+        return v.value
+
+    def slab_enable_dfsph(self): check(self.lib.fsa_slab_enable_dfsph(self._h))
 
     # -- measurement ------------------------------------------------------------------
     def timing_enable(self, on=True): check(self.lib.fsa_timing_enable(self._h, 1 if on else 0))

@@ -955,7 +955,8 @@ int fsa_timing_read(fsa_solver *hs, fsa_kernel_time *out, int cap, int *count) {
     int name(fsa_solver *hs) {                                                                       \
         Solver *s = reinterpret_cast<Solver *>(hs);                                                  \
         NEED(s);                                                                                     \
-        if (s->slab) return fail(FSA_ERR_INVALID, #name " is not available in a slab solver");       \
+        if (s->slab && !s->slab_carry_vstar)                                                         \
+            return fail(FSA_ERR_INVALID, #name ": a slab solver runs the DFSPH step only after fsa_slab_enable_dfsph"); \
         if (needs_sort && !s->sorted_valid) return fail(FSA_ERR_INVALID, #name " needs a sorted state"); \
         return launcher(s);                                                                          \
     }
@@ -970,7 +971,8 @@ DFSPH_ENTRY(fsa_update_velocities, launch_update_velocities, false)
 int fsa_update_position(fsa_solver *hs) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    if (s->slab) return fail(FSA_ERR_INVALID, "fsa_update_position is not available in a slab solver");
+    if (s->slab && !s->slab_carry_vstar)
+        return fail(FSA_ERR_INVALID, "fsa_update_position: a slab solver runs the DFSPH step only after fsa_slab_enable_dfsph");
     TRY(launch_update_position(s));
     // positions moved: the cell ranges no longer describe them
     s->sorted_valid = false;
@@ -1237,6 +1239,7 @@ int fsa_slab_enable_iisph(fsa_solver *hs, int n_global, const int *group, const 
     NEED(s);
     if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_enable_iisph needs a solver created with slab_nz > 0");
     if (n_global <= 0 || !group || !normal3) return fail(FSA_ERR_INVALID, "bad argument");
+    if (s->slab_carry_vstar) return fail(FSA_ERR_INVALID, "the solver is set up for the DFSPH step on slabs");
     FSA_HIP(counted_stream_sync(s->stream));
     const size_t N = (size_t)s->capacity, R = s->real_size(), G = (size_t)n_global;
     Buffers &b = s->b;
@@ -1266,12 +1269,24 @@ int fsa_slab_enable_iisph(fsa_solver *hs, int n_global, const int *group, const 
     return FSA_OK;
 }
 
+// ---- the DFSPH step on slab solvers ------------------------------------------------------------
+int fsa_slab_enable_dfsph(fsa_solver *hs) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_enable_dfsph needs a solver created with slab_nz > 0");
+    if (s->slab_carry) return fail(FSA_ERR_INVALID, "the solver is set up for the IISPH step on slabs");
+    if (s->pf.count) return fail(FSA_ERR_INVALID, "the solver is a member of a slab group");
+    s->slab_carry_vstar = true;
+    return FSA_OK;
+}
+
 int fsa_slab_pack_carry(fsa_solver *hs, const int own[2], const int keep[2], const int left[2], const int right[2],
                         void *d_send_left, void *d_extra_left, int cap_left, void *d_send_right, void *d_extra_right,
                         int cap_right, int counts[4]) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    if (!s->slab || !s->slab_carry) return fail(FSA_ERR_INVALID, "fsa_slab_pack_carry needs fsa_slab_enable_iisph first");
+    if (!s->slab || !(s->slab_carry || s->slab_carry_vstar))
+        return fail(FSA_ERR_INVALID, "fsa_slab_pack_carry needs fsa_slab_enable_iisph or fsa_slab_enable_dfsph first");
     if (!own || !keep || !left || !right || !counts) return fail(FSA_ERR_INVALID, "NULL argument");
     if (cap_left < 0 || cap_right < 0 || (cap_left > 0 && (!d_send_left || !d_extra_left)) ||
         (cap_right > 0 && (!d_send_right || !d_extra_right)))
@@ -1297,7 +1312,8 @@ int fsa_slab_pack_carry(fsa_solver *hs, const int own[2], const int keep[2], con
 int fsa_slab_unpack_carry(fsa_solver *hs, const void *d_records, const void *d_extras, int count) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     NEED(s);
-    if (!s->slab || !s->slab_carry) return fail(FSA_ERR_INVALID, "fsa_slab_unpack_carry needs fsa_slab_enable_iisph first");
+    if (!s->slab || !(s->slab_carry || s->slab_carry_vstar))
+        return fail(FSA_ERR_INVALID, "fsa_slab_unpack_carry needs fsa_slab_enable_iisph or fsa_slab_enable_dfsph first");
     if (count < 0 || (count > 0 && (!d_records || !d_extras))) return fail(FSA_ERR_INVALID, "bad record buffer");
     if ((long long)s->n + count > s->capacity)
         return fail(FSA_ERR_CAPACITY, "%d + %d particles exceed capacity %d", s->n, count, s->capacity);
@@ -1331,6 +1347,8 @@ static int slab_field(Solver *s, const char *name, void **ptr, int *reals) {
     else if (k == "pressure") *ptr = s->b.pressure;
     else if (k == "restDensity") *ptr = s->b.restDensity[s->cur];
     else if (k == "error") *ptr = s->b.error;
+    else if (k == "pstiff") *ptr = s->b.pstiff;
+    else if (k == "DF_factor") *ptr = s->b.DF_factor;
     else if (k == "v_star") { *ptr = s->b.v_star; *reals = 3; }
     else if (k == "dii") { *ptr = s->b.dii; *reals = 3; }
     else if (k == "dijpjl") { *ptr = s->b.dijpjl; *reals = 3; }
@@ -1368,6 +1386,19 @@ int fsa_slab_owned_sum(fsa_solver *hs, const char *name, const int own[2], doubl
     TRY(slab_field(s, name, &field, &reals));
     if (reals != 1) return fail(FSA_ERR_INVALID, "'%s' is not a scalar field", name);
     return launch_owned_sum(s, own[0], own[1], field, sum);
+}
+
+int fsa_slab_owned_max(fsa_solver *hs, const char *name, const int own[2], double start, double *max) {
+    Solver *s = reinterpret_cast<Solver *>(hs);
+    NEED(s);
+    if (!s->slab) return fail(FSA_ERR_INVALID, "fsa_slab_owned_max needs a solver created with slab_nz > 0");
+    if (!own || !max) return fail(FSA_ERR_INVALID, "NULL argument");
+    if (!s->sorted_valid) return fail(FSA_ERR_INVALID, "fsa_slab_owned_max needs a sorted state");
+    void *field = nullptr;
+    int reals = 1;
+    TRY(slab_field(s, name, &field, &reals));
+    if (reals != 1) return fail(FSA_ERR_INVALID, "'%s' is not a scalar field", name);
+    return launch_owned_max(s, own[0], own[1], field, start, max);
 }
 
 int fsa_slab_set_owned(fsa_solver *hs, const int own[2]) {

@@ -715,7 +715,9 @@ int launch_sort_fused(Solver *s, bool vstar_all) {
                        (Vec3<T> *)s->b.v_star_alt, s->b.blockLo, s->b.blockHi, f32 ? s->b.blockRows : nullptr,      \
                        s->b.bigBlocks, s->b.orderKey[in], s->b.orderKey[out], slots, s->b.undefBlockStart,              \
                        slots ? s->b.slabVars + kVarN : nullptr)
-        if (s->slab) {
+        if (s->slab && vstar_all && s->slab_carry_vstar) {  // (the DFSPH step on slabs goes on from v_star after the sort)
+            if (f32) FSA_RR(float, float4, true, true); else FSA_RR(double, double4, true, true);
+        } else if (s->slab) {
             if (f32) FSA_RR(float, float4, false, true); else FSA_RR(double, double4, false, true);
         } else if (f32) {
             if (vstar_all) FSA_RR(float, float4, true, false); else FSA_RR(float, float4, false, false);

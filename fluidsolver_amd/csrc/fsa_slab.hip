@@ -84,12 +84,14 @@ __device__ __forceinline__ unsigned route_outside(const SlabRanges &R, int layer
 
 constexpr int kPackItems = 4;  // particles per thread: one atomic per stream for 1024 particles
 
-// One more scalar per particle that travels with it (the pressure of the IISPH step, whose relaxation starts from
-// the last step's values): kept particles take it to the other copy, records to a buffer beside theirs, slot for
-// slot.  All null when nothing is carried.
+// One more field per particle that travels with it, `w` reals wide (the pressure of the IISPH step, whose relaxation
+// starts from the last step's values; the v_star of the DFSPH step, which the divergence loop after the sort goes on
+// from): kept particles take it to the other copy, records to a buffer beside theirs, slot for slot.  All null
+// when nothing is carried.
 template <typename T> struct SlabExtra {
     const T *in;
     T *out, *left, *right;
+    int w;
 };
 
 template <typename T>
@@ -174,7 +176,9 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
         const T rd = restDensityIn[i];
         const int uid = uniqueIdIn[i];
         const long long key = keyIn[i];
-        const T extra = X.in ? X.in[i] : (T)0;
+        T extra[3] = {(T)0, (T)0, (T)0};
+        if (X.in)
+            for (int c = 0; c < X.w; c++) extra[c] = X.in[(size_t)i * X.w + c];
         const int e = k * kWaves + wave;
         if (flags[k] & 1u) {
             const int slot = base[0] + part[0][e] + before[k][0];
@@ -184,7 +188,8 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
                 restDensityOut[slot] = rd;
                 uniqueIdOut[slot] = uid;
                 keyOut[slot] = key;
-                if (X.in) X.out[slot] = extra;
+                if (X.in)
+                    for (int c = 0; c < X.w; c++) X.out[(size_t)slot * X.w + c] = extra[c];
             }
         }
         if (flags[k] & 6u) {
@@ -198,14 +203,16 @@ __global__ __launch_bounds__(kBlock) void slab_pack_kernel(
                 const int slot = base[1] + part[1][e] + before[k][1];
                 if (slot < capLeft) {
                     sendLeft[slot] = rec;
-                    if (X.in) X.left[slot] = extra;
+                    if (X.in)
+                        for (int c = 0; c < X.w; c++) X.left[(size_t)slot * X.w + c] = extra[c];
                 }
             }
             if (flags[k] & 4u) {
                 const int slot = base[2] + part[2][e] + before[k][2];
                 if (slot < capRight) {
                     sendRight[slot] = rec;
-                    if (X.in) X.right[slot] = extra;
+                    if (X.in)
+                        for (int c = 0; c < X.w; c++) X.right[(size_t)slot * X.w + c] = extra[c];
                 }
             }
         }
@@ -262,11 +269,13 @@ __global__ __launch_bounds__(kBlock) void slab_unpack_kernel(int count, int at, 
                                                              Vec4<T> *__restrict__ velMass,
                                                              T *__restrict__ restDensity, int *__restrict__ uniqueId,
                                                              long long *__restrict__ key,
-                                                             const T *__restrict__ extras, T *__restrict__ extra) {
+                                                             const T *__restrict__ extras, T *__restrict__ extra,
+                                                             int w) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= count) return;
     const SlabRecord<T> r = recs[k];
-    if (extras) extra[at + k] = extras[k];
+    if (extras)
+        for (int c = 0; c < w; c++) extra[(size_t)(at + k) * w + c] = extras[(size_t)k * w + c];
     posType[at + k] = r.posType;
     velMass[at + k] = r.velMass;
     restDensity[at + k] = r.restDensity;
@@ -639,8 +648,9 @@ template <typename T>
 static int pack_t(Solver *s, const DevParams<T> &P, const SlabRanges &R, void *sendLeft, int capLeft, void *sendRight,
                   int capRight, void *extraLeft, void *extraRight) {
     const int in = s->cur, out = 1 - s->cur;
-    SlabExtra<T> X{nullptr, nullptr, nullptr, nullptr};
-    if (s->slab_carry) X = SlabExtra<T>{(const T *)s->b.pressure, (T *)s->b.pressure_alt, (T *)extraLeft, (T *)extraRight};
+    SlabExtra<T> X{nullptr, nullptr, nullptr, nullptr, 0};
+    if (s->slab_carry) X = SlabExtra<T>{(const T *)s->b.pressure, (T *)s->b.pressure_alt, (T *)extraLeft, (T *)extraRight, 1};
+    if (s->slab_carry_vstar) X = SlabExtra<T>{(const T *)s->b.v_star, (T *)s->b.v_star_alt, (T *)extraLeft, (T *)extraRight, 3};
     hipLaunchKernelGGL(slab_pack_kernel<T>, dim3((s->grid_n() + kBlock * kPackItems - 1) / (kBlock * kPackItems)), dim3(kBlock), 0, s->stream, P, s->grid_n(),
                        s->owned_from_sort ? 0 : 1, R, s->b.sortedHash, (const Vec4<T> *)s->b.posType[in],
                        (const Vec4<T> *)s->b.velMass[in], (const T *)s->b.restDensity[in], s->b.uniqueId[in],
@@ -665,6 +675,7 @@ int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int l
                      : pack_t<double>(s, s->pd, R, sendLeft, capLeft, sendRight, capRight, extraLeft, extraRight);
         if (rc) return rc;
         if (s->slab_carry) std::swap(s->b.pressure, s->b.pressure_alt);  // the kept particles' values went there
+        if (s->slab_carry_vstar) std::swap(s->b.v_star, s->b.v_star_alt);
     }
     FSA_HIP(hipMemcpyAsync(counts, s->b.slabCounters, 4 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     FSA_HIP(counted_stream_sync(s->stream));
@@ -702,12 +713,13 @@ int launch_slab_unpack(Solver *s, const void *recs, int count, const void *extra
         hipLaunchKernelGGL(slab_unpack_kernel<float>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, count, s->n,
                            (const SlabRecord<float> *)recs, (float4 *)s->b.posType[c], (float4 *)s->b.velMass[c],
                            (float *)s->b.restDensity[c], s->b.uniqueId[c], s->b.orderKey[c], (const float *)extras,
-                           (float *)s->b.pressure);
+                           (float *)(s->slab_carry_vstar ? s->b.v_star : s->b.pressure), s->slab_carry_vstar ? 3 : 1);
     else
         hipLaunchKernelGGL(slab_unpack_kernel<double>, dim3(blocks_for(count)), dim3(kBlock), 0, s->stream, count,
                            s->n, (const SlabRecord<double> *)recs, (double4 *)s->b.posType[c],
                            (double4 *)s->b.velMass[c], (double *)s->b.restDensity[c], s->b.uniqueId[c],
-                           s->b.orderKey[c], (const double *)extras, (double *)s->b.pressure);
+                           s->b.orderKey[c], (const double *)extras,
+                           (double *)(s->slab_carry_vstar ? s->b.v_star : s->b.pressure), s->slab_carry_vstar ? 3 : 1);
     FSA_HIP(hipGetLastError());
     return FSA_OK;
 }
@@ -832,12 +844,13 @@ __global__ __launch_bounds__(kBlock) void field_move_kernel(int count, int words
 
 // Sum of a[] over the particles this solver owns (cell layer in [lo, hi), or outside the grid), in double, block
 // partial sums folded in a fixed order.
-template <typename T>
+// (MAX: the maximum instead, from `start` on: the stop test of the DFSPH loops, solver/sph_solver.cu:176-180)
+template <typename T, bool MAX>
 __global__ __launch_bounds__(kBlock) void owned_sum_kernel(DevParams<T> P, int n, int lo, int hi,
                                                            const int *__restrict__ sortedHash, const T *__restrict__ a,
-                                                           double *__restrict__ part_out) {
+                                                           double *__restrict__ part_out, double start) {
     __shared__ double part[kBlock / 64];
-    double acc = 0.0;
+    double acc = MAX ? start : 0.0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const unsigned h = (unsigned)sortedHash[i];
         bool owned = h == (unsigned)FSA_GRID_UNDEF;
@@ -845,13 +858,16 @@ __global__ __launch_bounds__(kBlock) void owned_sum_kernel(DevParams<T> P, int n
             const int gz = (int)((h / (unsigned)P.gres[0]) % (unsigned)P.nz) + P.z0;
             owned = gz >= lo && gz < hi;
         }
-        if (owned) acc += (double)a[i];
+        if (owned) acc = MAX ? fmax(acc, (double)a[i]) : acc + (double)a[i];
     }
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double o = __shfl_xor(acc, d, 64);
+        acc = MAX ? fmax(acc, o) : acc + o;
+    }
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; w++) acc += part[w];
+        for (int w = 1; w < kBlock / 64; w++) acc = MAX ? fmax(acc, part[w]) : acc + part[w];
         part_out[blockIdx.x] = acc;
     }
 }
@@ -891,25 +907,36 @@ int launch_field_move(Solver *s, bool scatter, void *field, int words, const int
     return FSA_OK;
 }
 
-int launch_owned_sum(Solver *s, int lo, int hi, const void *a, double *out) {
-    *out = 0.0;
+static int owned_fold(Solver *s, int lo, int hi, const void *a, bool is_max, double start, double *out) {
+    *out = is_max ? start : 0.0;
     if (s->n == 0) return FSA_OK;
     const int nb = std::min(1024, blocks_for(s->n));
     double *tmp = (double *)s->b.reduce_tmp;
-    if (s->precision == FSA_PRECISION_F32)
-        hipLaunchKernelGGL(owned_sum_kernel<float>, dim3(nb), dim3(kBlock), 0, s->stream, s->pf, s->n, lo, hi, s->b.sortedHash,
-                           (const float *)a, tmp);
-    else
-        hipLaunchKernelGGL(owned_sum_kernel<double>, dim3(nb), dim3(kBlock), 0, s->stream, s->pd, s->n, lo, hi,
-                           s->b.sortedHash, (const double *)a, tmp);
+#define FSA_FOLD(T, P, MAX)                                                                                       \
+    hipLaunchKernelGGL((owned_sum_kernel<T, MAX>), dim3(nb), dim3(kBlock), 0, s->stream, P, s->n, lo, hi, s->b.sortedHash, \
+                       (const T *)a, tmp, start)
+    if (s->precision == FSA_PRECISION_F32) {
+        if (is_max) FSA_FOLD(float, s->pf, true); else FSA_FOLD(float, s->pf, false);
+    } else {
+        if (is_max) FSA_FOLD(double, s->pd, true); else FSA_FOLD(double, s->pd, false);
+    }
+#undef FSA_FOLD
     FSA_HIP(hipGetLastError());
     std::vector<double> h(nb);
     FSA_HIP(hipMemcpyAsync(h.data(), tmp, nb * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     FSA_HIP(counted_stream_sync(s->stream));
-    double sum = 0.0;
-    for (int b = 0; b < nb; b++) sum += h[b];
-    *out = sum;
+    double acc = is_max ? start : 0.0;
+    for (int b = 0; b < nb; b++) acc = is_max ? std::max(acc, h[b]) : acc + h[b];
+    *out = acc;
     return FSA_OK;
+}
+
+int launch_owned_sum(Solver *s, int lo, int hi, const void *a, double *out) {
+    return owned_fold(s, lo, hi, a, false, 0.0, out);
+}
+
+int launch_owned_max(Solver *s, int lo, int hi, const void *a, double start, double *out) {
+    return owned_fold(s, lo, hi, a, true, start, out);
 }
 
 }  // namespace fsa

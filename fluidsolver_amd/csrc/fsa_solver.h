@@ -124,6 +124,7 @@ struct Solver {
     int typenum = 0;            // columns of vFrac (0: no volume fractions given)
     bool iisph = false;         // the sort also carries pressure[] and refreshes groupSorted[]
     bool slab_carry = false;    // slab solver set up for the IISPH step: pack / unpack carry pressure[] (fsa_slab_enable_iisph)
+    bool slab_carry_vstar = false;  // z-slab solver prepared for the DFSPH step: v_star travels with the particles
     int table_n = 0;            // ... and its group / normal tables cover this many (global) unique ids
     int iisph_chain = 0;        // inside fsa_iisph_solve_pressure: 1 first round, 2 later rounds (fsa_iisph.hip)
     bool fluid_mass_uniform = false;  // fp32: every TYPE_FLUID particle has the same mass (checked where the host hands the masses over)
@@ -240,6 +241,7 @@ int launch_slab_pack(Solver *s, const int own[2], const int keep[2], const int l
 int launch_slab_unpack(Solver *s, const void *recs, int count, const void *extras = nullptr);
 int launch_slab_layer_indices(Solver *s, int lo, int hi, int *d_idx, int cap, int *count);  // synchronises
 int launch_field_move(Solver *s, bool scatter, void *field, int words, const int *d_idx, int count, void *d_buf);
+int launch_owned_max(Solver *s, int lo, int hi, const void *a, double start, double *out);
 int launch_owned_sum(Solver *s, int lo, int hi, const void *a, double *out);  // synchronises
 int launch_slab_edge_send(Solver *s, bool with_advect, const int own[2], const int left[2], const int right[2],
                           void *sendLeft, int sizeLeft, void *sendRight, int sizeRight);

@@ -333,30 +333,35 @@ class HipSlabBackend:
     def close(self):
         self.solver.close()
 
-    # -- the IISPH step (IisphSlabs below drives these) ------------------------------------------------
+    # -- the IISPH and DFSPH steps (IisphSlabs / DfsphSlabs below drive these) --------------------------
     real_bytes = 4
+    carry_width = 1  # reals that travel beside a record: the pressure (IISPH) or v_star (DFSPH)
 
     def enable_iisph(self, group, normal):
         self.solver.slab_enable_iisph(group, normal)
 
+    def enable_dfsph(self):
+        self.solver.slab_enable_dfsph()
+        self.carry_width = 3
+
     def pack_carry(self, own, keep, left, right, cap):
-        """-> kept, lost, {-1: (record bytes, pressures, count), +1: ...} for the sides that have a neighbour"""
+        """-> kept, lost, {-1: (record bytes, carried reals, count), +1: ...} for the sides that have a neighbour"""
         t = self.torch
-        rb = self.record_bytes
+        rb, w = self.record_bytes, self.carry_width
         sides = {-1: left[1] > left[0], 1: right[1] > right[0]}
-        if not hasattr(self, "_send") or self._send_cap != cap:
-            self._send_cap = cap
+        if not hasattr(self, "_send") or self._send_cap != (cap, w):
+            self._send_cap = (cap, w)
             self._send = {sd: (t.empty(max(cap, 1) * rb, dtype=t.uint8, device=self.device),
-                               t.empty(max(cap, 1), dtype=t.float32, device=self.device)) for sd in (-1, 1)}
+                               t.empty(max(cap, 1) * w, dtype=t.float32, device=self.device)) for sd in (-1, 1)}
         (bl, xl), (br, xr) = self._send[-1], self._send[1]
         kept, nl, nr, lost = self.solver.slab_pack_carry(own, keep, left, right, bl.data_ptr(), xl.data_ptr(),
                                                          cap if sides[-1] else 0, br.data_ptr(), xr.data_ptr(),
                                                          cap if sides[1] else 0)
         out = {}
         if sides[-1]:
-            out[-1] = (bl[:nl * rb], xl[:nl].view(t.uint8), nl)
+            out[-1] = (bl[:nl * rb], xl[:nl * w].view(t.uint8), nl)
         if sides[1]:
-            out[1] = (br[:nr * rb], xr[:nr].view(t.uint8), nr)
+            out[1] = (br[:nr * rb], xr[:nr * w].view(t.uint8), nr)
         return kept, lost, out
 
     def unpack_carry(self, records, extras, count):
@@ -402,6 +407,9 @@ class HipSlabBackend:
     def owned_error_sum(self, own):
         return self.solver.slab_owned_sum("error", own)
 
+    def owned_error_max(self, own, start):
+        return self.solver.slab_owned_max("error", own, start)
+
     def sort(self): self.solver.sort_particles()
     def setup_iisph(self): self.solver.setup_iisph()
     def iisph_factor(self): self.solver.iisph_factor()
@@ -410,9 +418,17 @@ class HipSlabBackend:
     def iisph_calc_dijpjl(self): self.solver.iisph_calc_dijpjl()
     def iisph_calc_new_pressure(self): self.solver.iisph_calc_new_pressure()
     def iisph_update(self): self.solver.iisph_update()
+    def dfsph_density_alpha(self): self.solver.compute_density_alpha()
+    def dfsph_npf(self): self.solver.compute_non_pressure_force()
+    def dfsph_solve_density_stiff(self): self.solver.solve_density_stiff()
+    def dfsph_solve_divergence_stiff(self): self.solver.solve_divergence_stiff()
+    def dfsph_apply_pstiff(self): self.solver.apply_pstiff()
+    def dfsph_update_position(self): self.solver.update_position()
+    def dfsph_update_velocities(self): self.solver.update_velocities()
 
 
-IISPH_FIELD_WIDTH = {"density": 1, "pressure": 1, "restDensity": 1, "v_star": 3, "dii": 3, "dijpjl": 3}
+IISPH_FIELD_WIDTH = {"density": 1, "pressure": 1, "restDensity": 1, "v_star": 3, "dii": 3, "dijpjl": 3, "pstiff": 1,
+                     "DF_factor": 1}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -660,6 +676,9 @@ class LocalComm:
     def sum(self, values):
         return float(sum(values))
 
+    def max(self, values):
+        return float(max(values))
+
 
 class DistComm:
     """One slab per process: buffers travel between z-neighbours over torch.distributed point-to-point calls
@@ -691,26 +710,19 @@ class DistComm:
         self.t.dist.all_reduce(t, group=self.t.group)
         return float(t.item())
 
+    def max(self, values):
+        torch = self.t.torch
+        t = torch.tensor([float(max(values))], dtype=torch.float64, device=self.t.comm_device)
+        self.t.dist.all_reduce(t, op=self.t.dist.ReduceOp.MAX, group=self.t.group)
+        return float(t.item())
 
-class IisphSlabs:
-    """MultiphaseSPHSolver::SolveIISPH (solver/MultiphaseSPHSolver.cpp:173-188; rounds: solver/sph_solver.cu:1409-1443)
-    on z-slabs: the slabs of `members` (SlabSolver objects built with iisph=True: all the slabs of the scene with a
-    LocalComm, or this process's one with a DistComm).
 
-    A step runs some 25 neighbour passes between two sorts, each reading what the pass before wrote at the
-    neighbours, so after every pass the fields it wrote are refreshed in the halo layers from the slab that owns
-    the particles: the sorted order of a slab is (y, layer, x, order key), so both slabs hold the particles of the
-    layers next to a cut in the same order, and a refresh is a gather on one side and a scatter on the other.  The
-    particle exchange after the integration is the WCSPH one with the pressure riding along (the relaxation of a step
-    starts from the pressures of the step before).  The mean of error[] that ends the pressure rounds is summed over
-    the particles each slab owns and then over the slabs.  Particle counts are known on the host here (one wait per
-    exchange and per round): the step is a dozen times longer than the WCSPH one."""
+class _FieldSlabs:
+    """What the IISPH and the DFSPH step on z-slabs share: the particle exchange with a field riding along, the lists
+    of the layers next to the cuts, the refresh of named fields in the halo layers from their owners."""
 
-    def __init__(self, members, comm, n_global, group, normal):
-        self.m, self.comm, self.n_global = list(members), comm, int(n_global)
-        for ss in self.m:
-            ss.backend.enable_iisph(group, normal)
-        self.rounds = []
+    def __init__(self, members, comm):
+        self.m, self.comm = list(members), comm
         self.lists = {}
 
     def _neighbours(self, ss):
@@ -733,7 +745,8 @@ class IisphSlabs:
             ss.backend.synchronize()
         inc = self.comm.swap_counts(counts)
         got_r = self.comm.swap_bytes(recs, {k: n * rb for k, n in inc.items()})
-        got_x = self.comm.swap_bytes(extras, {k: n * self.m[0].backend.real_bytes for k, n in inc.items()})
+        got_x = self.comm.swap_bytes(extras, {k: n * self.m[0].backend.real_bytes * self.m[0].backend.carry_width
+                                               for k, n in inc.items()})
         for ss in self.m:
             with ss.backend.stream_ctx():
                 for sd, peer in self._neighbours(ss):  # fixed order: left neighbour first
@@ -782,6 +795,28 @@ class IisphSlabs:
             with ss.backend.stream_ctx():
                 getattr(ss.backend, name)()
 
+
+class IisphSlabs(_FieldSlabs):
+    """MultiphaseSPHSolver::SolveIISPH (solver/MultiphaseSPHSolver.cpp:173-188; rounds: solver/sph_solver.cu:1409-1443)
+    on z-slabs: the slabs of `members` (SlabSolver objects built with iisph=True: all the slabs of the scene with a
+    LocalComm, or this process's one with a DistComm).
+
+    A step runs some 25 neighbour passes between two sorts, each reading what the pass before wrote at the
+    neighbours, so after every pass the fields it wrote are refreshed in the halo layers from the slab that owns
+    the particles: the sorted order of a slab is (y, layer, x, order key), so both slabs hold the particles of the
+    layers next to a cut in the same order, and a refresh is a gather on one side and a scatter on the other.  The
+    particle exchange after the integration is the WCSPH one with the pressure riding along (the relaxation of a step
+    starts from the pressures of the step before).  The mean of error[] that ends the pressure rounds is summed over
+    the particles each slab owns and then over the slabs.  Particle counts are known on the host here (one wait per
+    exchange and per round): the step is a dozen times longer than the WCSPH one."""
+
+    def __init__(self, members, comm, n_global, group, normal):
+        super().__init__(members, comm)
+        self.n_global = int(n_global)
+        for ss in self.m:
+            ss.backend.enable_iisph(group, normal)
+        self.rounds = []
+
     def setup(self):
         """SetupIISPH (solver/MultiphaseSPHSolver.cpp:850-860): sort, factor, rigid particle volumes"""
         self.exchange()  # hands out the halo copies
@@ -813,6 +848,58 @@ class IisphSlabs:
             self._each("iisph_factor")
             self._after_sort()
             self.refresh(["density", "dii"])
+
+
+class DfsphSlabs(_FieldSlabs):
+    """SPHSolver::SolveDFSPH (solver/sph_solver.cpp:108-120; the two correction loops: solver/sph_solver.cu:144-256) on
+    z-slabs, with the pattern of IisphSlabs: v_star is refreshed in the halo layers after computeNonPForce and after
+    every applyPStiff, pstiff after every solveDensityStiff / solveDivergenceStiff, density and DF_factor after
+    computeDensityAlpha; v_star rides with the exchange records (the divergence loop after the sort goes on from it);
+    a loop ends when the maximum of error[] over the owned particles of all slabs is below the threshold."""
+
+    def __init__(self, members, comm, maxiter=5, ethres=1.0):
+        super().__init__(members, comm)
+        self.maxiter, self.ethres = int(maxiter), float(ethres)
+        for ss in self.m:
+            ss.backend.enable_dfsph()
+        self.density_rounds, self.divergence_rounds = [], []
+
+    def _sorted(self):
+        self._each("sort")
+        self._each("dfsph_density_alpha")
+        self._after_sort()
+        self.refresh(["density", "DF_factor"])
+
+    def setup(self):
+        """SetupDFSPH (solver/sph_solver.cpp:102-106): sort + computeDensityAlpha"""
+        self.exchange()  # hands out the halo copies
+        self._sorted()
+
+    def _loop(self, solve, start):
+        applied = 0
+        for _it in range(self.maxiter):
+            self._each(solve)
+            self.refresh(["pstiff"])
+            worst = self.comm.max([ss.backend.owned_error_max(ss.own, start) for ss in self.m])
+            if worst < self.ethres:  # solver/sph_solver.cu:176-180
+                break
+            self._each("dfsph_apply_pstiff")
+            self.refresh(["v_star"])
+            applied += 1
+        return applied
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            self._each("dfsph_npf")
+            self.refresh(["v_star"])
+            self.density_rounds.append(self._loop("dfsph_solve_density_stiff", -9999.0))
+            self._each("dfsph_update_position")
+            self.exchange()
+            self._sorted()
+            self._each("dfsph_solve_divergence_stiff")  # the extra first launch of solver/sph_solver.cu:226
+            self.refresh(["pstiff"])
+            self.divergence_rounds.append(self._loop("dfsph_solve_divergence_stiff", 0.0))
+            self._each("dfsph_update_velocities")
 
 
 def derive_grid(P):

@@ -195,7 +195,7 @@ int fsa_set_buffer(fsa_solver *s, const char *name, const void *src, size_t byte
  * The other step of the reference's SPHSolver (solver/sph_solver.cpp:100-120), one entry per
  * launcher of solver/sph_solver.cu:119-256.  Extra named buffers for fsa_get_buffer /
  * fsa_set_buffer: DF_factor, pstiff, error (n reals each).  All need a sorted state except the two
- * integration kernels.  Not available in slab solvers (v_star does not travel with the records).
+ * integration kernels.  In slab solvers only after fsa_slab_enable_dfsph (further down).
  */
 /* computeDensityAlpha: poly6 density and the DFSPH factor */
 int fsa_compute_density_alpha(fsa_solver *s);
@@ -419,12 +419,26 @@ int fsa_slab_unpack_carry(fsa_solver *s, const void *d_records, const void *d_ex
  * must be layers this solver holds, into the device array d_idx (cap ints); needs a sorted state.  Synchronises. */
 int fsa_slab_layer_indices(fsa_solver *s, int layer_lo, int layer_hi, int *d_idx, int cap, int *count);
 /* d_out[e] = field[d_idx[e]] / field[d_idx[e]] = d_in[e], device buffers; fields: density, pressure, restDensity,
- * error (one real per particle), v_star, dii, dijpjl (three).  Queued on the solver's stream. */
+ * error, pstiff, DF_factor (one real per particle), v_star, dii, dijpjl (three).  Queued on the solver's stream. */
 int fsa_slab_gather_field(fsa_solver *s, const char *name, const int *d_idx, int count, void *d_out);
 int fsa_slab_scatter_field(fsa_solver *s, const char *name, const int *d_idx, int count, const void *d_in);
 /* Sum (in double) of a scalar field over the particles this solver owns: cell layer in [own[0], own[1]) at the
  * last sort, or outside the grid.  Synchronises. */
 int fsa_slab_owned_sum(fsa_solver *s, const char *name, const int own[2], double *sum);
+/* ... and the maximum of `start` and the field's values over the same particles.  Synchronises. */
+int fsa_slab_owned_max(fsa_solver *s, const char *name, const int own[2], double start, double *max);
+
+/* The DFSPH step on z-slabs (SPHSolver::SolveDFSPH, solver/sph_solver.cpp:108-120, for a scene cut along z).  As for
+ * the IISPH step, the fields a neighbour pass wrote are refreshed in the halo layers after the pass with
+ * fsa_slab_layer_indices / fsa_slab_gather_field / fsa_slab_scatter_field: v_star after computeNonPForce and after
+ * every applyPStiff, pstiff after every solveDensityStiff / solveDivergenceStiff, density and DF_factor after
+ * computeDensityAlpha.  fsa_slab_enable_dfsph opens the DFSPH stage calls to a slab solver and makes v_star travel
+ * with the particles: the sort reorders it for every particle, and fsa_slab_pack_carry / fsa_slab_unpack_carry carry
+ * it beside the records (three reals per record; the divergence loop after the sort goes on from it).  The stop
+ * test of a correction loop is the maximum of error[] over the particles every slab owns (fsa_slab_owned_max, then
+ * the maximum over the slabs).  fluidsolver_amd/slabs.py (DfsphSlabs) drives it; a solver is set up for one of the
+ * two steps, not both. */
+int fsa_slab_enable_dfsph(fsa_solver *s);
 
 /* The whole of that for slabs that all belong to solvers of THIS process (one host program driving a node, as the
  * reference's main.cpp drives one GPU): replaces SetupIISPH / SolveIISPH (solver/MultiphaseSPHSolver.cpp:850-860,

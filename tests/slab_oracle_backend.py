@@ -192,7 +192,8 @@ class OracleSlabBackend:
         return self._layer_of_hash(self.sorted_hash)
 
 
-IISPH_FIELD_WIDTH = {"density": 1, "pressure": 1, "restDensity": 1, "v_star": 3, "dii": 3, "dijpjl": 3}
+IISPH_FIELD_WIDTH = {"density": 1, "pressure": 1, "restDensity": 1, "v_star": 3, "dii": 3, "dijpjl": 3, "pstiff": 1,
+                     "DF_factor": 1}
 
 
 class OracleIisphSlabBackend(OracleSlabBackend):
@@ -200,6 +201,7 @@ class OracleIisphSlabBackend(OracleSlabBackend):
     exchange the slab's particles live in one oracle state, on which the driver runs the oracle's stage functions;
     the field refresh and the pressure that rides along with the records are restated in numpy"""
     real_bytes = 4
+    carry_width = 1
 
     def __init__(self, orc, params_dict, held, capacity):
         super().__init__(orc, params_dict, held, capacity)
@@ -323,3 +325,76 @@ class OracleIisphSlabBackend(OracleSlabBackend):
         if self.st is not None:
             self.st.close()
             self.st = None
+
+
+class OracleDfsphSlabBackend(OracleIisphSlabBackend):
+    """... and for the DFSPH step on slabs (fluidsolver_amd.slabs.DfsphSlabs): what rides with the records is v_star
+    (three reals), kept here in the array the IISPH stand-in keeps the pressure in"""
+    carry_width = 3
+
+    def enable_dfsph(self):
+        self.group_g = None
+        self.pressure = np.zeros((self.n, 3), np.float32)
+
+    def upload(self, sub):
+        OracleSlabBackend.upload(self, sub)
+        self.pressure = np.zeros((self.n, 3), np.float32)
+
+    def _flush(self):
+        if self.st is None:
+            return
+        for k in ("pos", "vel", "type", "mass", "restDensity"):
+            self.a[k] = self.st[k].copy()
+        self.a["uniqueId"] = self.uid_sorted
+        self.pressure = self.st["v_star"].copy()
+        self.st.close()
+        self.st = None
+
+    def pack_carry(self, own, keep, left, right, cap):
+        kept, lost, out = super().pack_carry(own, keep, left, right, cap)
+        return kept, lost, out
+
+    def unpack_carry(self, records, extras, count):
+        if count:
+            self.unpack(records, count)
+            self.pressure = np.concatenate([self.pressure, extras.numpy().view(np.float32)[:3 * count].reshape(-1, 3)])
+
+    def sort(self):
+        self._flush()
+        order = np.argsort(self.key.astype(np.uint64), kind="stable")
+        self.a = {name: v[order] for name, v in self.a.items()}
+        uid = self.a["uniqueId"]
+        st = self.orc.new_state(self.n, self.num_cells)
+        load = {k: self.a[k] for k in ("pos", "vel", "type", "mass", "restDensity")}
+        load.update(v_star=self.pressure[order])
+        st.load(load)
+        st.sort_particles(self.p)
+        h = st["particleHash"].copy()
+        self.uid_sorted = uid[st["uniqueId"]]
+        n = len(h)
+        first = np.ones(n, bool)
+        first[1:] = h[1:] != h[:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(n), 0))
+        self.key = (h.astype(np.int64) << 32) | (np.arange(n) - start)
+        self.sorted_hash = h
+        self.st = st
+
+    def dfsph_density_alpha(self): self.st.compute_density_alpha(self.p)
+    def dfsph_npf(self): self.st.compute_non_pressure_force(self.p)
+    def dfsph_solve_density_stiff(self): self.st.solve_density_stiff(self.p)
+    def dfsph_solve_divergence_stiff(self): self.st.solve_divergence_stiff(self.p)
+    def dfsph_apply_pstiff(self): self.st.apply_pstiff(self.p)
+    def dfsph_update_position(self): self.st.update_position(self.p)
+    def dfsph_update_velocities(self): self.st.update_velocities(self.p)
+
+    def owned_error_max(self, own, start):
+        layer = self._layer_of_hash(self.sorted_hash)
+        m = (layer < 0) | ((layer >= own[0]) & (layer < own[1]))
+        e = self.st["error"][m]
+        e = e[~np.isnan(e)]
+        return float(max(np.float32(start), e.max())) if len(e) else float(np.float32(start))
+
+    def get(self, name):
+        if name == "v_star" and self.st is None:
+            return self.pressure
+        return super().get(name)

@@ -93,6 +93,16 @@ def owned_iisph(ss):
     return out
 
 
+def owned_dfsph(ss):
+    """what a slab owns after DFSPH steps (each ends with the velocity update that follows the sort)"""
+    b = ss.backend
+    layer = b.global_layer_of_sorted()
+    m = ((layer >= ss.own[0]) & (layer < ss.own[1])) | (layer < 0)
+    out = {k: np.asarray(b.get(k))[m] for k in ("pos", "vel", "density", "v_star", "DF_factor", "uniqueId", "type")}
+    out["hash_layer"] = layer[m]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", choices=sorted(SCENES), default="dam")
@@ -104,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--recut-at", type=int, default=0, help="re-cut the slabs after this many steps")
-    ap.add_argument("--mode", choices=["wcsph", "iisph"], default="wcsph")
+    ap.add_argument("--mode", choices=["wcsph", "iisph", "dfsph"], default="wcsph")
     ap.add_argument("--group", choices=["none", "hosted"], default="none",
                     help="hosted: the library's one-slab-per-process group, its messages over this job's gloo group")
     a = ap.parse_args()
@@ -117,11 +127,11 @@ def main():
     sc = SCENES[a.scene]()
     if a.backend == "oracle":
         from oracle.orc import Oracle
-        from slab_oracle_backend import OracleIisphSlabBackend, OracleSlabBackend
+        from slab_oracle_backend import OracleDfsphSlabBackend, OracleIisphSlabBackend, OracleSlabBackend
         orc = Oracle("f32")
         orc.set_threads(2)
         device = torch.device("cpu")
-        cls = OracleIisphSlabBackend if a.mode == "iisph" else OracleSlabBackend
+        cls = {"iisph": OracleIisphSlabBackend, "dfsph": OracleDfsphSlabBackend}.get(a.mode, OracleSlabBackend)
         factory = lambda P, held, cap: cls(orc, P, held, cap)  # noqa: E731
     else:
         device = torch.device("cuda", 0)
@@ -134,6 +144,19 @@ def main():
         cuts = [0] + [3 * (r + 1) for r in range(a.world - 1)] + [gz]
     if a.scene == "drift" and not a.recut_at:
         cuts = DRIFT_CUTS[a.world]
+    if a.mode == "dfsph":
+        ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts, exchange_buffers=False)
+        team = slabs.DfsphSlabs([ss], slabs.DistComm(tr))
+        team.setup()
+        team.step(a.steps)
+        out = owned_dfsph(ss)
+        out.update(cuts=np.asarray(ss.layout.cuts), lost=np.asarray(ss.lost), sent=np.asarray(ss.sent_records),
+                   density_rounds=np.asarray(team.density_rounds), divergence_rounds=np.asarray(team.divergence_rounds))
+        np.savez(os.path.join(a.out, f"rank{a.rank}.npz"), **out)
+        ss.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if a.mode == "iisph":
         ss = slabs.SlabSolver(sc, a.rank, a.world, tr, factory, cuts=cuts, exchange_buffers=False)
         team = slabs.IisphSlabs([ss], slabs.DistComm(tr), len(sc["pos"]), sc["group"], sc["normal"])

@@ -244,6 +244,39 @@ def assert_same_iisph_bits(parts, ref):
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_dfsph_slab_run_equals_undivided_run(orc32, tmp_path, world):
+    """SolveDFSPH on slabs: v_star riding with the records, a field refresh after every neighbour pass, the maximum
+    of error[] taken over the slabs.  Every owned particle must carry the bits of the undivided oracle run, and both
+    correction loops must run the same number of rounds in every step"""
+    from slab_worker import SCENES
+    steps = 6
+    parts = run_ranks(world, "oracle", steps, tmp_path, scene="dam", mode="dfsph")
+    assert sum(int(p["lost"]) for p in parts) == 0
+    assert sum(int(p["sent"]) for p in parts) > 0
+    sc = SCENES["dam"]()
+    p, st = oracle_pair(orc32, sc)
+    st.sort_particles(p)
+    st.compute_density_alpha(p)
+    dens, div = [], []
+    for _ in range(steps):
+        st.compute_non_pressure_force(p)
+        dens.append(st.correct_density_error(p, 5, 1.0)[0])
+        st.sort_particles(p)
+        st.compute_density_alpha(p)
+        div.append(st.correct_divergence_error(p, 5, 1.0)[0])
+    for part in parts:
+        assert part["density_rounds"].tolist() == dens and part["divergence_rounds"].tolist() == div
+    uid = np.concatenate([q["uniqueId"] for q in parts])
+    order = np.argsort(uid, kind="stable")
+    ro = np.argsort(st["uniqueId"], kind="stable")
+    assert np.array_equal(uid[order], st["uniqueId"][ro])
+    for k in ("pos", "vel", "density", "v_star", "DF_factor", "type"):
+        a, b = np.concatenate([q[k] for q in parts])[order], st[k][ro]
+        assert np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes(), f"{k} differs from the undivided run"
+    st.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
 def test_iisph_slab_run_equals_undivided_run(orc32, tmp_path, world):
     """the step main.cpp runs (SolveIISPH) on slabs: a field refresh after every neighbour pass, the pressure riding
     with the records, the stop test summed over the slabs; tank walls (TYPE_RIGID) in every slab.  Every owned
