@@ -54,7 +54,8 @@ EXPORTS = (
     "fsa_grid_team_advect_particles", "fsa_grid_team_body_force", "fsa_grid_team_make_rhs",
     "fsa_grid_team_div_velocity", "fsa_grid_team_solve", "fsa_grid_team_update_u", "fsa_grid_team_step",
     "fsa_grid_team_sync", "fsa_grid_team_create_hosted", "fsa_slab_group_create_hosted", "fsa_slab_enable_dfsph",
-    "fsa_slab_owned_max",
+    "fsa_slab_owned_max", "fsa_slab_dfsph_create_local", "fsa_slab_dfsph_setup", "fsa_slab_dfsph_step",
+    "fsa_slab_dfsph_stats", "fsa_slab_dfsph_destroy",
 )
 
 
@@ -212,6 +213,11 @@ def load() -> C.CDLL:
         "fsa_grid_team_create_hosted": [C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
         "fsa_slab_enable_dfsph": [H],
+        "fsa_slab_dfsph_create_local": [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.POINTER(C.c_void_p)],
+        "fsa_slab_dfsph_setup": [H], "fsa_slab_dfsph_step": [H, C.c_int], "fsa_slab_dfsph_destroy": [H],
+        "fsa_slab_dfsph_stats": [H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int],
         "fsa_slab_owned_max": [H, C.c_char_p, C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_double)],
         "fsa_slab_group_create_hosted": [H, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)],
@@ -862,6 +868,40 @@ class SlabIisphTeam:
     def close(self):
         if self._h:
             self.lib.fsa_slab_iisph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SlabDfsphTeam:
+    """fsa_slab_dfsph_*: the DFSPH step on slabs that all live in this process (the solvers must have been prepared
+    with Solver.slab_enable_dfsph and hold the particles they own)."""
+
+    def __init__(self, solvers, cuts, halo, record_cap, maxiter=5, ethres=1.0):
+        self.lib = load()
+        self.solvers = list(solvers)
+        arr = (C.c_void_p * len(self.solvers))(*[s._h for s in self.solvers])
+        self._h = C.c_void_p()
+        check(self.lib.fsa_slab_dfsph_create_local(len(self.solvers), arr, (C.c_int * len(cuts))(*cuts), int(halo),
+                                                   int(record_cap), int(maxiter), float(ethres), C.byref(self._h)))
+
+    def setup(self): check(self.lib.fsa_slab_dfsph_setup(self._h))
+    def step(self, nsteps=1): check(self.lib.fsa_slab_dfsph_step(self._h, int(nsteps)))
+
+    def stats(self, last_rounds=0):
+        """-> (steps, lost, records_sent, [density-loop rounds], [divergence-loop rounds]) of the last steps; waits"""
+        st, lo, se = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        a, b = (C.c_int * max(last_rounds, 1))(), (C.c_int * max(last_rounds, 1))()
+        check(self.lib.fsa_slab_dfsph_stats(self._h, C.byref(st), C.byref(lo), C.byref(se), a, b, int(last_rounds)))
+        return st.value, lo.value, se.value, list(a)[:last_rounds], list(b)[:last_rounds]
+
+    def close(self):
+        if self._h:
+            self.lib.fsa_slab_dfsph_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -15,6 +15,11 @@
 //
 // Results equal the single solver's for every particle, bit for bit (ties inside a cell by order key, as in every
 // slab run), and the rounds are the same in number.
+//
+// The DFSPH step (SPHSolver::SolveDFSPH, solver/sph_solver.cpp:108-120; loops: solver/sph_solver.cu:144-256) runs
+// on the same machinery with other fields: v_star rides with the records (three reals) and is refreshed after
+// computeNonPForce and every applyPStiff, pstiff after every solve*Stiff, density and DF_factor after
+// computeDensityAlpha; a correction loop ends on the maximum of error[] over all slabs' owned particles.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -46,6 +51,11 @@ struct TeamMember {
 };
 
 struct Team {
+    int mode = 0;     // 0 the IISPH step, 1 the DFSPH step
+    int carry_w = 1;  // reals beside a record: the pressure / v_star
+    int maxiter = 5;  // DFSPH: rounds of a correction loop at most, and its threshold
+    double ethres = 1.0;
+    std::vector<int> rounds2;  // DFSPH: rounds of the divergence loop (`rounds`: of the density loop)
     int world = 0, halo = 0, record_cap = 0, rb = 0, n_global = 0;
     size_t real = 4;
     std::vector<int> cuts;
@@ -83,8 +93,10 @@ constexpr int kFieldRealsMax = 7;  // the widest refresh: density + dii + restDe
 
 static int team_member_setup(Team &t, TeamMember &mb, Solver *s, int rank) {
     if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
-    if (!s->slab || !s->slab_carry)
+    if (t.mode == 0 && (!s->slab || !s->slab_carry))
         return fail(FSA_ERR_INVALID, "slab %d: the IISPH step on slabs needs slab solvers prepared by fsa_slab_enable_iisph", rank);
+    if (t.mode == 1 && (!s->slab || !s->slab_carry_vstar))
+        return fail(FSA_ERR_INVALID, "slab %d: the DFSPH step on slabs needs slab solvers prepared by fsa_slab_enable_dfsph", rank);
     if (s->pf.count) return fail(FSA_ERR_INVALID, "slab %d: the solver is a member of a slab group", rank);
     mb.s = s;
     mb.rank = rank;
@@ -105,9 +117,9 @@ static int team_member_setup(Team &t, TeamMember &mb, Solver *s, int rank) {
     for (int d = 0; d < 2; d++) {
         if (!mb.has[d]) continue;
         FSA_HIP(hipMalloc((void **)&mb.send[d], cap * t.rb));
-        FSA_HIP(hipMalloc((void **)&mb.sendx[d], cap * t.real));
+        FSA_HIP(hipMalloc((void **)&mb.sendx[d], cap * t.real * t.carry_w));
         FSA_HIP(hipMalloc((void **)&mb.recv[d], cap * t.rb));
-        FSA_HIP(hipMalloc((void **)&mb.recvx[d], cap * t.real));
+        FSA_HIP(hipMalloc((void **)&mb.recvx[d], cap * t.real * t.carry_w));
         // the layers next to a cut hold fewer particles than a message may carry (record_cap covers 2 halo widths)
         FSA_HIP(hipMalloc((void **)&mb.edge[d], cap * sizeof(int)));
         FSA_HIP(hipMalloc((void **)&mb.halo[d], cap * sizeof(int)));
@@ -155,7 +167,8 @@ static int team_exchange(Team &t) {
             const char *recs = peer.send[1 - d], *extras = peer.sendx[1 - d];
             if (peer.s->device != s->device) {  // (the sender's pack has finished: it waited for its counts)
                 FSA_HIP(hipMemcpyPeerAsync(mb.recv[d], s->device, recs, peer.s->device, (size_t)cnt * t.rb, s->stream));
-                FSA_HIP(hipMemcpyPeerAsync(mb.recvx[d], s->device, extras, peer.s->device, (size_t)cnt * t.real, s->stream));
+                FSA_HIP(hipMemcpyPeerAsync(mb.recvx[d], s->device, extras, peer.s->device, (size_t)cnt * t.real * t.carry_w,
+                                           s->stream));
                 recs = mb.recv[d];
                 extras = mb.recvx[d];
             }
@@ -216,6 +229,8 @@ static int team_field(Solver *s, const char *name, FieldRef &f) {
     else if (k == "v_star") { f.ptr = s->b.v_star; f.words = 3 * w; }
     else if (k == "dii") { f.ptr = s->b.dii; f.words = 3 * w; }
     else if (k == "dijpjl") { f.ptr = s->b.dijpjl; f.words = 3 * w; }
+    else if (k == "pstiff") f.ptr = s->b.pstiff;
+    else if (k == "DF_factor") f.ptr = s->b.DF_factor;
     if (!f.ptr) return fail(FSA_ERR_UNKNOWN_NAME, "field '%s'", name);
     return FSA_OK;
 }
@@ -329,22 +344,73 @@ static int team_step(Team &t) {
     return FSA_OK;
 }
 
-}  // namespace fsa
+// ---- the DFSPH step ---------------------------------------------------------------------------------------
+static int team_dfsph_sorted(Team &t) {
+    int rc = team_each(t, fsa_sort_particles);
+    if (!rc) rc = team_each(t, fsa_compute_density_alpha);
+    if (!rc) rc = team_after_sort(t);
+    if (!rc) rc = team_refresh(t, {"density", "DF_factor"});
+    return rc;
+}
 
-using namespace fsa;
+// one correction loop (solver/sph_solver.cu:160-185 / :226-250): rounds of solve*Stiff, the test on the maximum of
+// error[] over all owned particles, applyPStiff; *applied = applyPStiff passes done
+static int team_dfsph_loop(Team &t, int (*solve)(fsa_solver *), double start, int *applied) {
+    *applied = 0;
+    for (int iter = 0; iter < t.maxiter; iter++) {
+        int rc = team_each(t, solve);
+        if (!rc) rc = team_refresh(t, {"pstiff"});
+        if (rc) return rc;
+        double worst = start;
+        for (TeamMember &mb : t.m) {
+            FSA_HIP(hipSetDevice(mb.s->device));
+            double part = start;
+            rc = launch_owned_max(mb.s, mb.own[0], mb.own[1], mb.s->b.error, start, &part);  // waits
+            if (rc) return rc;
+            worst = std::max(worst, part);
+        }
+        if (worst < t.ethres) break;
+        rc = team_each(t, fsa_apply_pstiff);
+        if (!rc) rc = team_refresh(t, {"v_star"});
+        if (rc) return rc;
+        (*applied)++;
+    }
+    return FSA_OK;
+}
 
-extern "C" {
+static int team_step_dfsph(Team &t) {
+    int rc = team_each(t, fsa_compute_non_pressure_force);
+    if (!rc) rc = team_refresh(t, {"v_star"});
+    int dens = 0, div = 0;
+    if (!rc) rc = team_dfsph_loop(t, fsa_solve_density_stiff, -9999.0, &dens);
+    if (!rc) rc = team_each(t, fsa_update_position);
+    if (!rc) rc = team_exchange(t);
+    if (!rc) rc = team_dfsph_sorted(t);
+    if (!rc) rc = team_each(t, fsa_solve_divergence_stiff);  // the extra first launch of solver/sph_solver.cu:226
+    if (!rc) rc = team_refresh(t, {"pstiff"});
+    if (!rc) rc = team_dfsph_loop(t, fsa_solve_divergence_stiff, 0.0, &div);
+    if (!rc) rc = team_each(t, fsa_update_velocities);
+    if (rc) return rc;
+    if (t.rounds.size() >= 8192) {
+        t.rounds.erase(t.rounds.begin(), t.rounds.begin() + 4096);
+        t.rounds2.erase(t.rounds2.begin(), t.rounds2.begin() + 4096);
+    }
+    t.rounds.push_back(dens);
+    t.rounds2.push_back(div);
+    t.steps++;
+    return FSA_OK;
+}
 
-int fsa_slab_iisph_create_local(int world, fsa_solver **solvers, const int *cuts, int halo, int record_cap,
-                                int n_global, fsa_slab_iisph **out) {
-    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
-    *out = nullptr;
+static int team_create(int mode, int world, fsa_solver **solvers, const int *cuts, int halo, int record_cap, int n_global,
+                       Team **out) {
     if (world < 1 || !solvers || !cuts || halo < 1 || record_cap < 0 || n_global < 1) return fail(FSA_ERR_INVALID, "bad argument");
     for (int r = 0; r < world; r++)
         if (cuts[r + 1] - cuts[r] < halo + 1)
             return fail(FSA_ERR_INVALID, "slab %d has %d layers, fewer than halo + 1 = %d", r, cuts[r + 1] - cuts[r], halo + 1);
     Team *t = new (std::nothrow) Team();
     if (!t) return fail(FSA_ERR_NOMEM, "out of host memory");
+    t->mode = mode;
+    t->carry_w = mode == 1 ? 3 : 1;
     t->world = world;
     t->halo = halo;
     t->record_cap = record_cap;
@@ -364,6 +430,23 @@ int fsa_slab_iisph_create_local(int world, fsa_solver **solvers, const int *cuts
             return rc;
         }
     }
+    *out = t;
+    return FSA_OK;
+}
+
+}  // namespace fsa
+
+using namespace fsa;
+
+extern "C" {
+
+int fsa_slab_iisph_create_local(int world, fsa_solver **solvers, const int *cuts, int halo, int record_cap,
+                                int n_global, fsa_slab_iisph **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    Team *t = nullptr;
+    int rc = team_create(0, world, solvers, cuts, halo, record_cap, n_global, &t);
+    if (rc) return rc;
     *out = reinterpret_cast<fsa_slab_iisph *>(t);
     return FSA_OK;
 }
@@ -371,6 +454,7 @@ int fsa_slab_iisph_create_local(int world, fsa_solver **solvers, const int *cuts
 int fsa_slab_iisph_setup(fsa_slab_iisph *ht) {
     Team *t = reinterpret_cast<Team *>(ht);
     if (!t) return fail(FSA_ERR_INVALID, "team is NULL");
+    if (t->mode != 0) return fail(FSA_ERR_INVALID, "not a team of the IISPH step");
     int rc = team_exchange(*t);  // hands out the halo copies
     if (!rc) rc = team_each(*t, fsa_setup_iisph);
     if (!rc) rc = team_after_sort(*t);
@@ -384,6 +468,7 @@ int fsa_slab_iisph_step(fsa_slab_iisph *ht, int nsteps) {
     Team *t = reinterpret_cast<Team *>(ht);
     if (!t) return fail(FSA_ERR_INVALID, "team is NULL");
     if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    if (t->mode != 0) return fail(FSA_ERR_INVALID, "not a team of the IISPH step");
     if (!t->set_up) return fail(FSA_ERR_INVALID, "fsa_slab_iisph_step needs fsa_slab_iisph_setup first");
     for (int k = 0; k < nsteps; k++) {
         int rc = team_step(*t);
@@ -410,6 +495,65 @@ int fsa_slab_iisph_stats(fsa_slab_iisph *ht, long long *steps, long long *lost, 
         }
     return FSA_OK;
 }
+
+int fsa_slab_dfsph_create_local(int world, fsa_solver **solvers, const int *cuts, int halo, int record_cap, int maxiter,
+                                double ethres, fsa_slab_dfsph **out) {
+    if (!out) return fail(FSA_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (maxiter < 0) return fail(FSA_ERR_INVALID, "maxiter < 0");
+    Team *t = nullptr;
+    int rc = team_create(1, world, solvers, cuts, halo, record_cap, 1, &t);
+    if (rc) return rc;
+    t->maxiter = maxiter;
+    t->ethres = ethres;
+    *out = reinterpret_cast<fsa_slab_dfsph *>(t);
+    return FSA_OK;
+}
+
+int fsa_slab_dfsph_setup(fsa_slab_dfsph *ht) {
+    Team *t = reinterpret_cast<Team *>(ht);
+    if (!t) return fail(FSA_ERR_INVALID, "team is NULL");
+    if (t->mode != 1) return fail(FSA_ERR_INVALID, "not a team of the DFSPH step");
+    int rc = team_exchange(*t);  // hands out the halo copies
+    if (!rc) rc = team_dfsph_sorted(*t);  // SetupDFSPH, solver/sph_solver.cpp:102-106
+    if (rc) return rc;
+    t->set_up = true;
+    return FSA_OK;
+}
+
+int fsa_slab_dfsph_step(fsa_slab_dfsph *ht, int nsteps) {
+    Team *t = reinterpret_cast<Team *>(ht);
+    if (!t) return fail(FSA_ERR_INVALID, "team is NULL");
+    if (nsteps < 0) return fail(FSA_ERR_INVALID, "nsteps < 0");
+    if (t->mode != 1) return fail(FSA_ERR_INVALID, "not a team of the DFSPH step");
+    if (!t->set_up) return fail(FSA_ERR_INVALID, "fsa_slab_dfsph_step needs fsa_slab_dfsph_setup first");
+    for (int k = 0; k < nsteps; k++) {
+        int rc = team_step_dfsph(*t);
+        if (rc) return rc;
+    }
+    return FSA_OK;
+}
+
+int fsa_slab_dfsph_stats(fsa_slab_dfsph *ht, long long *steps, long long *lost, long long *records_sent, int *density_rounds,
+                         int *divergence_rounds, int rounds_cap) {
+    Team *t = reinterpret_cast<Team *>(ht);
+    if (!t) return fail(FSA_ERR_INVALID, "team is NULL");
+    for (TeamMember &mb : t->m) {
+        FSA_HIP(hipSetDevice(mb.s->device));
+        FSA_HIP(counted_stream_sync(mb.s->stream));
+    }
+    if (steps) *steps = t->steps;
+    if (lost) *lost = t->lost;
+    if (records_sent) *records_sent = t->sent;
+    for (int k = 0; k < rounds_cap; k++) {  // of the last rounds_cap steps, oldest first
+        const long long i = (long long)t->rounds.size() - rounds_cap + k;
+        if (density_rounds) density_rounds[k] = i >= 0 ? t->rounds[(size_t)i] : 0;
+        if (divergence_rounds) divergence_rounds[k] = i >= 0 && (size_t)i < t->rounds2.size() ? t->rounds2[(size_t)i] : 0;
+    }
+    return FSA_OK;
+}
+
+int fsa_slab_dfsph_destroy(fsa_slab_dfsph *ht) { return fsa_slab_iisph_destroy(reinterpret_cast<fsa_slab_iisph *>(ht)); }
 
 int fsa_slab_iisph_destroy(fsa_slab_iisph *ht) {
     Team *t = reinterpret_cast<Team *>(ht);

@@ -229,6 +229,13 @@ void MultiphaseSPHSolver::SetupDFSPH() {
     SetupFluidScene();
     run_mode = DFSPH;
     if (numParticles > 0) {
+        // several z-slabs under this one host program (slab_mode.cpp): the set-up runs on them
+        if (const char *slabs = std::getenv("FSA_SLABS"))
+            if (std::atoi(slabs) > 0) {
+                EnterSlabModeIISPH(std::atoi(slabs), true);
+                CopyPosColorFromDevice();
+                return;
+            }
         check(fsa_setup_dfsph(device), "SetupDFSPH");
         CopyPosColorFromDevice();
     }

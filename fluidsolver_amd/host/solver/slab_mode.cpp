@@ -73,7 +73,7 @@ void SPHSolver::LeaveSlabMode() {
 // nslabs slabs and `device` is released.
 void SPHSolver::EnterSlabMode(int nslabs) {
     if (run_mode != SPH) {
-        std::fprintf(stderr, "FSA_SLABS: only the SPH (WCSPH) and IISPH steps run on several slabs\n");
+        std::fprintf(stderr, "FSA_SLABS: this entry is the SPH (WCSPH) step's (the IISPH and DFSPH steps enter slab mode from their own set-up)\n");
         std::exit(EXIT_FAILURE);
     }
     const int n = numParticles;
@@ -189,7 +189,9 @@ void SPHSolver::EnterSlabMode(int nslabs) {
 // is cut into slabs, `device` is released, and the rest of the set-up (factors, rigid particle volumes: :857-858)
 // runs on the slabs.  A particle keeps its unique id; group and normal, which the step reads of a neighbour and which
 // never change, go to every slab as tables over all ids.
-void SPHSolver::EnterSlabModeIISPH(int nslabs) {
+// dfsph: the DFSPH step instead (called at the start of SetupDFSPH with the scene as uploaded; v_star rides with the
+// particles, no tables); the set-up that follows (sort, computeDensityAlpha) runs on the slabs.
+void SPHSolver::EnterSlabModeIISPH(int nslabs, bool dfsph) {
     const int n = numParticles;
     const int gz = hParam.gridres[2];
     if (nslabs < 1 || gz < nslabs * (kHalo + 1)) {
@@ -280,18 +282,28 @@ void SPHSolver::EnterSlabModeIISPH(int nslabs) {
                          sm.data(), srd.data()),
               "fsa_upload (slab)");
         check(fsa_set_scene_has_rigid(s, rigid ? 1 : 0), "fsa_set_scene_has_rigid");
-        check(fsa_slab_enable_iisph(s, n, group.data(), normal.data()), "fsa_slab_enable_iisph");
+        if (dfsph) check(fsa_slab_enable_dfsph(s), "fsa_slab_enable_dfsph");
+        else check(fsa_slab_enable_iisph(s, n, group.data(), normal.data()), "fsa_slab_enable_iisph");
     }
-    check(fsa_slab_iisph_create_local(nslabs, slab_devices.data(), slab_cuts.data(), kHalo, (int)record_cap, n, &slab_team),
-          "fsa_slab_iisph_create_local");
-    check(fsa_slab_iisph_setup(slab_team), "fsa_slab_iisph_setup");
+    slab_team_dfsph = dfsph;
+    if (dfsph) {  // 5 rounds at most, threshold 1: SolveDFSPH, solver/sph_solver.cpp:108-120
+        check(fsa_slab_dfsph_create_local(nslabs, slab_devices.data(), slab_cuts.data(), kHalo, (int)record_cap, 5, 1.0,
+                                          &slab_team),
+              "fsa_slab_dfsph_create_local");
+        check(fsa_slab_dfsph_setup(slab_team), "fsa_slab_dfsph_setup");
+    } else {
+        check(fsa_slab_iisph_create_local(nslabs, slab_devices.data(), slab_cuts.data(), kHalo, (int)record_cap, n, &slab_team),
+              "fsa_slab_iisph_create_local");
+        check(fsa_slab_iisph_setup(slab_team), "fsa_slab_iisph_setup");
+    }
     std::printf("%d particles on %d z-slabs (cuts", n, nslabs);
     for (int c : slab_cuts) std::printf(" %d", c);
-    std::printf("), capacity %lld each, IISPH step\n", capacity);
+    std::printf("), capacity %lld each, %s step\n", capacity, dfsph ? "DFSPH" : "IISPH");
 }
 
 void SPHSolver::StepSlabs() {
-    if (slab_team) check(fsa_slab_iisph_step(slab_team, 1), "fsa_slab_iisph_step");
+    if (slab_team && slab_team_dfsph) check(fsa_slab_dfsph_step(slab_team, 1), "fsa_slab_dfsph_step");
+    else if (slab_team) check(fsa_slab_iisph_step(slab_team, 1), "fsa_slab_iisph_step");
     else check(fsa_slab_group_step(slab_group, 1), "fsa_slab_group_step");
 }
 

@@ -36,7 +36,8 @@ protected:
     // FSA_SLABS=N (slab_mode.cpp): the scene on N z-slab solvers driven as one group, `device` released
     std::vector<fsa_solver *> slab_devices;
     fsa_slab_group *slab_group = nullptr;
-    fsa_slab_iisph *slab_team = nullptr;  // ... or, for the IISPH step, as a team (fsa_slab_iisph_*)
+    fsa_slab_iisph *slab_team = nullptr;  // ... or, for the IISPH and DFSPH steps, as a team (fsa_slab_iisph_* / _dfsph_*)
+    bool slab_team_dfsph = false;
     std::vector<int> slab_cuts;
     vecf4 slab_color;  // colours by slab id
     fsa_params hParam{};           // replaces the global hParam (solver/sph_kernel_impl.cuh:13)
@@ -83,7 +84,7 @@ public:
     int AddDefaultParticle();
 
     void EnterSlabMode(int nslabs);
-    void EnterSlabModeIISPH(int nslabs);
+    void EnterSlabModeIISPH(int nslabs, bool dfsph = false);
     void LeaveSlabMode();
     void StepSlabs();
     void CopyPosColorFromSlabs();

@@ -439,6 +439,19 @@ int fsa_slab_owned_max(fsa_solver *s, const char *name, const int own[2], double
  * the maximum over the slabs).  fluidsolver_amd/slabs.py (DfsphSlabs) drives it; a solver is set up for one of the
  * two steps, not both. */
 int fsa_slab_enable_dfsph(fsa_solver *s);
+/* ... and for the slabs of one process the library drives it, as fsa_slab_iisph_* does the IISPH step (further
+ * down): solvers prepared by fsa_slab_enable_dfsph, `maxiter` rounds per correction loop at most, threshold `ethres`
+ * (the reference: 5 and 1).  setup = SetupDFSPH (hands out the halo copies, sort, computeDensityAlpha).  stats waits
+ * for the members' streams; density_rounds / divergence_rounds (either may be NULL): applyPStiff passes of the two
+ * loops in the last rounds_cap steps, oldest first. */
+typedef struct fsa_slab_iisph fsa_slab_dfsph; /* the same kind of team, running the other step */
+int fsa_slab_dfsph_create_local(int world, fsa_solver **solvers, const int *cuts, int halo, int record_cap, int maxiter,
+                                double ethres, fsa_slab_dfsph **out);
+int fsa_slab_dfsph_setup(fsa_slab_dfsph *t);
+int fsa_slab_dfsph_step(fsa_slab_dfsph *t, int nsteps);
+int fsa_slab_dfsph_stats(fsa_slab_dfsph *t, long long *steps, long long *lost, long long *records_sent, int *density_rounds,
+                         int *divergence_rounds, int rounds_cap);
+int fsa_slab_dfsph_destroy(fsa_slab_dfsph *t);
 
 /* The whole of that for slabs that all belong to solvers of THIS process (one host program driving a node, as the
  * reference's main.cpp drives one GPU): replaces SetupIISPH / SolveIISPH (solver/MultiphaseSPHSolver.cpp:850-860,

@@ -350,13 +350,19 @@ def test_headless_program_iisph_on_slabs_equals_single_solver(tmp_path, slabs):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not have_bins(), reason="host layer not built")
-def test_headless_program_refuses_dfsph_on_slabs(tmp_path):
+@pytest.mark.parametrize("slabs", [2, 3])
+def test_headless_program_dfsph_on_slabs_equals_single_solver(tmp_path, slabs):
+    """FSA_SLABS=N FSA_RUN_MODE=DFSPH: the read-back of the last frame is that of the single-solver run, byte for byte"""
+    exe = os.path.join(HOST, "bin", "particle_solver")
     e = env_for(20)
-    e.update(FSA_RUN_MODE="DFSPH", FSA_SLABS="2")
-    r = subprocess.run([os.path.join(HOST, "bin", "particle_solver"), "--frames", "1"], env=e, capture_output=True,
-                       text=True, timeout=300)
-    # (the DFSPH step ignores FSA_SLABS: it runs on the single solver and says nothing of slabs)
-    assert r.returncode == 0 and "z-slabs" not in r.stdout
+    e["FSA_RUN_MODE"] = "DFSPH"
+    a, b = tmp_path / "single.bin", tmp_path / "slabs.bin"
+    subprocess.check_call([exe, "--frames", "8", "--save-final", str(a)], env=e, stdout=subprocess.DEVNULL, timeout=300)
+    r = subprocess.run([exe, "--frames", "8", "--save-final", str(b)], env=dict(e, FSA_SLABS=str(slabs)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert f"on {slabs} z-slabs" in r.stdout and "DFSPH step" in r.stdout
+    assert a.read_bytes() == b.read_bytes()
 
 
 def grid_tracers():

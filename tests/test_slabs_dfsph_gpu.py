@@ -61,6 +61,31 @@ def test_dfsph_on_local_slabs_equals_plain_solver(world, scene, variant):
         ss.close()
 
 
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_library_team_equals_plain_solver(world):
+    """the same step driven inside the library (fsa_slab_dfsph_*: what the host program uses for FSA_SLABS=N with the
+    DFSPH step), refreshes ordered by events instead of host waits"""
+    sc = SCENES["ddam"]()
+    ref, dens, div = plain_dfsph_run(sc, STEPS, 3)
+    ranks = [slabs.SlabSolver(sc, r, world, None, lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, 3),
+                              exchange_buffers=False) for r in range(world)]
+    for ss in ranks:
+        ss.backend.enable_dfsph()
+    team = capi.SlabDfsphTeam([ss.backend.solver for ss in ranks], ranks[0].layout.cuts, slabs.HALO,
+                              max(ss.record_cap for ss in ranks))
+    team.setup()
+    team.step(2)
+    team.step(STEPS - 2)
+    steps, lost, sent, got_dens, got_div = team.stats(STEPS)
+    assert steps == STEPS and lost == 0 and got_dens == dens and got_div == div
+    if world > 1:
+        assert sent > 0
+    assert_same_dfsph_bits([owned_dfsph(ss) for ss in ranks], ref)
+    team.close()
+    for ss in ranks:
+        ss.close()
+
+
 def test_dfsph_two_ranks_over_gloo_equal_plain_solver(tmp_path):
     parts = run_ranks(2, "hip", STEPS, tmp_path, variant=3, scene="dam", mode="dfsph")
     assert sum(int(p["lost"]) for p in parts) == 0
