@@ -673,13 +673,11 @@ def torch_host_transport(group=None):
     return tr
 
 
-torch_grid_transport = torch_host_transport
-
 
 class GridTeam:
     """fsa_grid_team: the grid solver on z-slabs.  Fields go in and out in the single solver's layout (the whole
     grid).  GridTeam(dim, cuts, ...) holds all slabs in this process; GridTeam.rccl(...) holds slab `rank`, and so
-    does GridTeam.hosted(...) with a caller-supplied transport (torch_grid_transport)."""
+    does GridTeam.hosted(...) with a caller-supplied transport (torch_host_transport)."""
 
     FACE, CELL = GridSolver.FACE, GridSolver.CELL
 
