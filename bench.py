@@ -311,10 +311,15 @@ def main():
                    **{k: res[k] for k in ("comm_backend", "slab_step", "slab_cuts", "halo_layers",
                                           "max_local_particles", "mean_local_particles", "lost_particles",
                                           "records_sent_per_step", "exchange_ms_per_step_max",
-                                          "host_syncs_in_timed_steps", "recuts", "recut_every") if k in res}},
+                                          "host_syncs_in_timed_steps", "recuts", "recut_every",
+                                          "sum_owned_particles") if k in res}},
         "roofline": roof, "roofline_all": {"unit": "GB/s", "peak": HBM_PEAK_GBS, "kernels": roof_all},
         "kernels": kernels,
     }
+    if res.get("sum_owned_particles", res["n"]) != res["n"] or res.get("lost_particles", 0):
+        # a slab run whose ranks do not own every particle exactly once between them has timed something else
+        raise SystemExit(f"bench: {res.get('sum_owned_particles')} of {res['n']} particles owned after the run, "
+                         f"{res.get('lost_particles')} dropped by a full exchange buffer")
     single = args.gpus == 1 and world == 1 and "local_n" not in res
     if single and args.jitter == 0 and not os.environ.get("FSA_BENCH_NO_DEVELOPED"):
         # the headline state is a lattice that has barely moved; the same scene in a disordered state, the fluid

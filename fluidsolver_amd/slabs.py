@@ -1147,9 +1147,11 @@ def _bench_distributed(args, build_scene):
     local_n = ss.backend.n
     types = ss.backend.get("type")
     local_fluid = int((types == 0).sum())
+    layer = ss.backend.global_layer_of_sorted()
+    owned_n = int((((layer >= ss.own[0]) & (layer < ss.own[1])) | (layer < 0)).sum())
     exch_ms = sum(ms for k, (c, ms) in kt.items() if k in ("slab_pack", "edge_send", "exchange", "slab_unpack", "unpack_hash")) / max(args.steps, 1)
     stats = torch.tensor([wall, float(local_n), float(lost), float(ss.backend.solver.num_undef()), float(sent),
-                          exch_ms, float(host_waits)], dtype=torch.float64, device=sync_dev)
+                          exch_ms, float(host_waits), float(owned_n)], dtype=torch.float64, device=sync_dev)
     mx = stats.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone()
@@ -1163,7 +1165,7 @@ def _bench_distributed(args, build_scene):
                           if hosted else "library slab group (RCCL send/recv, no host round trip)") if native else
                          "torch.distributed transport, two host round trips per step",
                exchange_ms_per_step_max=float(mx[5]), host_syncs_in_timed_steps=int(mx[6]),
-               recuts=ss.recuts - recuts0, recut_every=recut_every)
+               recuts=ss.recuts - recuts0, recut_every=recut_every, sum_owned_particles=int(sm[7]))
     if native:
         group.close()
     ss.close()

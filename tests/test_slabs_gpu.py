@@ -175,3 +175,4 @@ def test_bench_ends_non_zero_when_the_rccl_group_cannot_be_made(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["config"]["comm_backend"] == "gloo"
     assert "staged through the host" in line["config"]["slab_step"] and line["config"]["lost_particles"] == 0
+    assert line["config"]["sum_owned_particles"] == line["config"]["particles_total"]
