@@ -411,7 +411,10 @@ class Solver:
     def synchronize(self): check(self.lib.fsa_synchronize(self._h))
     def set_stream(self, stream_ptr): check(self.lib.fsa_set_stream(self._h, C.c_void_p(stream_ptr)))
     def set_variant(self, v: int): check(self.lib.fsa_set_variant(self._h, int(v)))
-    def set_neighbour_lists(self, on: bool): check(self.lib.fsa_set_neighbour_lists(self._h, int(bool(on))))
+    def set_neighbour_lists(self, on, replay: bool = True):
+        """on: the passes that repeat between two sorts replay recorded neighbours instead of searching;
+        replay=False: from neighbour lists only, never from the hit record of the variant-3 density pass"""
+        check(self.lib.fsa_set_neighbour_lists(self._h, (1 if replay else 2) if on else 0))
 
     # -- DFSPH ------------------------------------------------------------------------
     def compute_density_alpha(self): check(self.lib.fsa_compute_density_alpha(self._h))

@@ -139,7 +139,7 @@ static void free_all(Solver *s) {
                     b.error, b.reduce_tmp, b.aux4, b.pd, b.pressure_alt, b.dii, b.dijpjl, b.pressureForce, b.aii,
                     b.density_star, b.groupSorted, b.vFrac, b.densArr, b.hash, b.slot,
                     b.tmpIndex, b.tmpHash, b.sortedIndex, b.sortedHash, b.cellCount, b.cellStart, b.gridCellStart,
-                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.blockLo, b.blockHi, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.wallCount, b.wallList, b.wallForce, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
+                    b.gridCellEnd, b.blockRows, b.bigBlocks, b.blockLo, b.blockHi, b.nbList, b.nbCount, b.hitWords, b.hitCount, b.wallCount, b.wallList, b.wallForce, b.applyRec, b.scanTmp, b.undefBlockCount, b.undefBlockStart, b.color, b.normal, b.group,
                     b.indexTable, b.orderKey[0], b.orderKey[1], b.slabCounters, b.slabVars};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -294,6 +294,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
 #ifdef FSA_ABLATE
     if (const char *e = getenv("FSA_FAST_DBG")) s->dbg_fast = atoi(e);
 #endif
+    if (const char *e = getenv("FSA_HIT_REPLAY")) s->use_replay = atoi(e) != 0;
     if (const char *e = getenv("FSA_WALL_PASS")) s->wall_mode = atoi(e) == 0 ? 1 : 2;
 
     int rc = activate(s);
@@ -345,6 +346,7 @@ int fsa_create(const fsa_params *p, int precision, int capacity, int device, fsa
         ALLOC(b.wallCount, (nblocks + 8) * kTunedBS, true);
         ALLOC(b.wallList, (N + 8) * sizeof(int), true);
         ALLOC(b.wallForce, (N + 8) * 4 * sizeof(float), false);
+        ALLOC(b.applyRec, (N + 8) * 4 * sizeof(float), false);
     }
     ALLOC(b.scanTmp, scan_tiles * sizeof(int), true);
     ALLOC(b.undefBlockCount, (nblocks + 8) * sizeof(int), true);
@@ -1457,7 +1459,9 @@ int fsa_set_variant(fsa_solver *hs, int variant) {
 int fsa_set_neighbour_lists(fsa_solver *hs, int enabled) {
     Solver *s = reinterpret_cast<Solver *>(hs);
     if (!s) return fail(FSA_ERR_INVALID, "solver is NULL");
+    if (enabled < 0 || enabled > 2) return fail(FSA_ERR_INVALID, "fsa_set_neighbour_lists: %d is neither 0, 1 nor 2", enabled);
     s->use_lists = enabled != 0;
+    s->use_replay = enabled == 1;
     s->lists_valid = false;
     return FSA_OK;
 }

@@ -18,6 +18,7 @@ namespace fsa {
 // ---- DensityAlphaCell :582-624 + computeDensityAlpha_kernel :626-660 -------------------------------
 template <typename T> struct AlphaPolicy {
     static constexpr bool kDeepReplay = true;
+    static constexpr bool kHitReplay = sizeof(T) == 4;
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T dens, mwij, mx, my, mz, mass; };
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(kBlock) void pack_npf_kernel(int n, float two_visc,
 
 struct NpfFastPolicy {
     using T = float;
+    static constexpr bool kHitReplay = true;
+    static constexpr bool kWallWords = true;
     static __device__ __forceinline__ int reach(int tj) { return NpfPolicy<float>::reach(tj); }
     struct Self { ForceSelf<float> F, Fb; };
     struct Nb { float4 r; };
@@ -178,6 +181,7 @@ __device__ __forceinline__ float4 apply_record(const float4 &p, float w) {
 // FAST (fp32, variant 2): hardware reciprocal square root and fused multiply-adds, about 1e-7 relative per term
 template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct StiffPolicy {
     static constexpr bool kDeepReplay = FAST;
+    static constexpr bool kHitReplay = FAST && PACKED;  // (the row tiles of the list kernel bring 1 %: 10.8 -> 10.6 ms per step)
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T acc; Vec3<T> vs; };
@@ -270,6 +274,7 @@ template <typename T, bool TIMES_DT, bool PACKED, bool FAST = false> struct Stif
 // no ordering hazard between threads.
 template <typename T, bool PACKED, bool FAST = false> struct ApplyPolicy {
     static constexpr bool kDeepReplay = FAST;
+    static constexpr bool kHitReplay = FAST && PACKED;
     // which neighbour types count: 1 = inside the support, 2 = anywhere in the 27 cells, 0 = never
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T wi, fx, fy, fz; };
@@ -330,6 +335,7 @@ struct ApplyUniformPolicy {
     using T = float;
     static constexpr bool kPosInNb = true;
     static constexpr bool kDeepReplay = true;
+    static constexpr bool kHitReplay = true;
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T wi, fx, fy, fz, mass; };
     struct Nb {
@@ -535,6 +541,13 @@ int launch_non_pressure_force(Solver *s) {
 }
 
 static bool apply_uniform(const Solver *s) { return use_fast(s) && s->fluid_mass_uniform && s->b.hitWords; }
+// Where the records of ApplyUniformPolicy live: in the buffer of the WCSPH hit record (which is stale after that)
+// when this step does not replay it, else in a buffer of their own.
+static float4 *apply_records(Solver *s) {
+    if (replays_hits<ApplyUniformPolicy>(s) && s->b.applyRec) return (float4 *)s->b.applyRec;
+    s->hits_valid = false;
+    return (float4 *)s->b.hitWords;
+}
 
 // The tuned passes read packed records that a small kernel writes first.  Inside fsa_correct_density_error /
 // fsa_correct_divergence_error (Solver::dfsph_chain) the passes hand the records on to each other instead: a
@@ -545,13 +558,12 @@ template <typename Policy> static int run_stiff(Solver *s, const char *tag) {
         int rc = pack_vstar_mass(s);
         if (rc) return rc;
     }
-    int rc = ensure_lists(s);
+    int rc = ensure_neighbours<Policy>(s);
     if (rc) return rc;
     PassArrays<float> A = arrays_of<float>(s);
     if (s->dfsph_chain) {
         if (apply_uniform(s)) {
-            s->hits_valid = false;  // the records live in the buffer of the WCSPH hit record, which this step does not use
-            A.recOut = (float4 *)s->b.hitWords;
+            A.recOut = apply_records(s);
         } else {
             s->pd_valid = false;  // the buffer is shared with the WCSPH force pass
             A.rec2Out = (float *)s->b.pd;
@@ -591,18 +603,18 @@ int launch_apply_pstiff(Solver *s) {
     if (s->n == 0) return FSA_OK;
     if (apply_uniform(s)) {
         const bool chained = s->dfsph_chain == 2;  // the density-change pass before has written the records
+        int rc = ensure_neighbours<ApplyUniformPolicy>(s);  // (before the records: the hit record may share their buffer)
+        if (rc) return rc;
+        float4 *const recs = apply_records(s);
         if (!chained) {
             ScopedTimer t(s, "pack_pstiff_mass");
-            s->hits_valid = false;
             hipLaunchKernelGGL(pack_apply_record_kernel, dim3(blocks_for(s->n)), dim3(kBlock), 0, s->stream, s->n,
                                (const float4 *)s->b.posType[s->cur], (const float *)s->b.pstiff,
-                               (const float *)s->b.density, (float4 *)s->b.hitWords);
+                               (const float *)s->b.density, recs);
             FSA_HIP(hipGetLastError());
         }
-        int rc = ensure_lists(s);
-        if (rc) return rc;
         PassArrays<float> A = arrays_of<float>(s);
-        A.aux4b = (const float4 *)s->b.hitWords;
+        A.aux4b = recs;
         if (chained) A.recOut = (float4 *)s->b.aux4;
         ScopedTimer t(s, "apply_pstiff");
         return run_tiled<ApplyUniformPolicy>(s, A, true);
@@ -617,7 +629,7 @@ int launch_apply_pstiff(Solver *s) {
                                (const float4 *)s->b.velMass[s->cur], (float2 *)s->b.pd);
             FSA_HIP(hipGetLastError());
         }
-        int rc = ensure_lists(s);
+        int rc = use_fast(s) ? ensure_neighbours<ApplyPolicy<float, true, true>>(s) : ensure_lists(s);
         if (rc) return rc;
         PassArrays<float> A = arrays_of<float>(s);
         if (chained) A.recOut = (float4 *)s->b.aux4;

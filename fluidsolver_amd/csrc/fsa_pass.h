@@ -69,6 +69,19 @@ template <typename Policy, typename = void> struct row_replay : std::false_type 
 template <typename Policy> struct row_replay<Policy, std::void_t<decltype(Policy::kRowReplay)>>
     : std::bool_constant<Policy::kRowReplay> {};
 
+// `static constexpr bool kHitReplay = true`: between two sorts the pass replays the hit record of the WCSPH density
+// pass (bit masks per neighbour row, fsa_tile.h) from row tiles in LDS (hit_replay_kernel) instead of a neighbour
+// list.  For policies that reach TYPE_FLUID neighbours inside the support only, skip the particle itself, and
+// read nothing of a neighbour beyond Nb and the position.
+template <typename Policy, typename = void> struct hit_replay : std::false_type {};
+template <typename Policy> struct hit_replay<Policy, std::void_t<decltype(Policy::kHitReplay)>>
+    : std::bool_constant<Policy::kHitReplay> {};
+// ... `static constexpr bool kWallWords = true` beside it: the policy also reaches the TYPE_BOUNDARY particles of the
+// 27 cells, wherever they are (reach() == 2); the record lists those for every fluid particle in words of their own.
+template <typename Policy, typename = void> struct wall_words : std::false_type {};
+template <typename Policy> struct wall_words<Policy, std::void_t<decltype(Policy::kWallWords)>>
+    : std::bool_constant<Policy::kWallWords> {};
+
 // One particle against its 27 cells in the reference's order, neighbours from global memory.
 template <typename T, typename Policy>
 __device__ __forceinline__ void generic_walk(const DevParams<T> &P, const PassArrays<T> &A, int index,
@@ -615,6 +628,233 @@ __global__ __launch_bounds__(BS, FSA_ROWS_BLOCKS) void list_rows_kernel(DevParam
     if (active) Policy::finish(A, P, index, S);
 }
 
+// The replay of the recorded hits (see hit_replay above).  The record of fsa_sph_fast.hip marks, for every particle
+// and every neighbour row (or segment) of its workgroup's block, which of the row's fluid particles lie inside the
+// support on the fused squared distance, the particle itself left out: one 57-candidate word per row in registers,
+// nothing searched, no list entries to decode, and no load inside the loops but the tile reads.  The rows stream
+// through LDS as in list_rows_kernel (positions and Nb records, coalesced loads, double buffered; a lane may lag one
+// row behind the block), the policy's `pair` applies the reference's own tests to every marked neighbour, in
+// neighbour order.  Particles without a record (kHitOverflow; every particle of a block that cannot be tiled) walk
+// the cells.  Blocks per CU: as the WCSPH force replay, which has this structure and is bound by latency.
+#ifndef FSA_REPLAY_BLOCKS
+#define FSA_REPLAY_BLOCKS 6
+#endif
+template <typename Nb, int ROWCAP, bool POS> struct ReplayLds {
+    RowShared<1, 4, false> sh;  // only its row table is used here
+    Segments sg;
+    float4 pos[POS ? 2 * ROWCAP : 1];  // two tiles: segment s lives in tile s & 1
+    Nb nb[2 * ROWCAP];
+};
+template <typename Policy, int BS, int ROWCAP>
+__global__ __launch_bounds__(BS, FSA_REPLAY_BLOCKS) void hit_replay_kernel(DevParams<float> P, int n, PassArrays<float> A,
+                                                        const int *__restrict__ cellStart,
+                                                        const int *__restrict__ sortedHash,
+                                                        const uint2 *__restrict__ hitWords,
+                                                        const unsigned char *__restrict__ hitCount,
+                                                        const unsigned char *__restrict__ wallCount, int run_log) {
+    using Nb = typename Policy::Nb;
+    constexpr bool kPos = !pos_in_nb<Policy>::value;  // positions in a tile of their own
+    constexpr int kRegs = row_regs<BS, ROWCAP - kChunk>();
+    constexpr int kQuorum = 40;
+    __shared__ ReplayLds<Nb, ROWCAP, kPos> lds;
+    static_assert((kPos ? sizeof(float4) : sizeof(Nb)) * 2 * ROWCAP >= sizeof(int) * (20 * kSparseRuns + 16),
+                  "a tile is the scratch space of sparse_segments");
+    if (P.halt && *P.halt) return;  // see DevParams::halt
+    Segments &sg = lds.sg;
+    const int tid = threadIdx.x;
+    const int blk = xcd_block(run_log);
+    const int b0 = blk * BS;
+    if (b0 >= n) return;  // padding blocks of the rounded-up grid
+    const int nb = min(BS, n - b0);
+    const int index = b0 + tid;
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool active = false;
+    if (index < n) {
+        pi = A.posType[index];
+        active = Policy::wants(unpack_int(pi.w));
+        if (!active) Policy::skip(A, P, index);
+    }
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // e.g. a block of wall particles
+    // the same tiles as the pass that recorded: the block's rows, or segments of its own
+    const int cls = setup_rows<ROWCAP>(P, b0, nb, cellStart, sortedHash, lds.sh, 0u, 0u, P.rows);
+    bool staged = cls != 0;
+    if (staged) setup_segments<ROWCAP>(lds.sh, cls, sg);
+    else if (P.rows[(size_t)blk * kRowTableStride + 19])
+        staged = sparse_segments<ROWCAP>(P, b0, nb, sortedHash, cellStart,
+                                         reinterpret_cast<int *>(kPos ? (void *)lds.pos : (void *)lds.nb), sg);
+    typename Policy::Self S;
+    int cnt = 0;       // extra words of the lane's record
+    bool rec = false;  // the lane has a record
+    if (active) {
+        Policy::init(A, P, index, S);
+        cnt = hitCount[index];
+        rec = cnt != kHitOverflow;
+        if (!rec) generic_walk<float, Policy>(P, A, index, pi, cellStart, S);
+    }
+    if (!rec) cnt = 0;
+    if (staged) {
+        const uint2 *const wp = hitWords + (size_t)blk * kHitSlots * BS + tid;
+        constexpr unsigned kNoSeg = 0xffffu;
+        auto extra_at = [&](int k) { return k < cnt ? wp[(size_t)(kMaxSegs + k) * BS] : make_uint2(0u, kNoSeg << kHitSegShift); };
+        int xk = 0;                  // extra words taken so far
+        uint2 xw = extra_at(0);      // the next one
+        unsigned cur = 0, pend = 0;  // bits at hand (32 candidates from `cbase` on), and the 25 after them
+        int cseg = -1;               // the segment they belong to
+        int cbase = 0;               // tile entry of bit 31 of `cur`, the two tiles counted through
+        struct Stage {
+            float4 p;
+            Nb nb;
+        };
+        Stage e[kRegs];
+        auto fetch = [&](int s, int len) {
+            const int last = len > 0 ? len - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < kRegs; k++) {
+                const int j = s + min(tid + k * BS, last);
+                if constexpr (kPos) e[k].p = A.posType[j];
+                e[k].nb = Policy::load(A, j);
+            }
+        };
+        auto store = [&](int buf, int len) {
+#pragma unroll
+            for (int k = 0; k < kRegs; k++) {
+                const int i = tid + k * BS;
+                if (i < len) {
+                    if constexpr (kPos) lds.pos[buf * ROWCAP + i] = e[k].p;
+                    lds.nb[buf * ROWCAP + i] = e[k].nb;
+                }
+            }
+        };
+        __syncthreads();  // the segment table is visible
+        fetch(sg.start[0], sg.len[0]);
+        uint2 fw = rec ? wp[0] : make_uint2(0u, 0u);  // main word of the segment whose loop runs
+        store(0, sg.len[0]);
+        __syncthreads();
+        const int nseg = sg.count;
+        if (nseg > 1) fetch(sg.start[1], sg.len[1]);
+        for (int r = 0; r < nseg; r++) {
+            uint2 fwn = make_uint2(0u, 0u);
+            if (r + 1 < nseg && rec) fwn = wp[(size_t)(r + 1) * BS];  // in flight during this segment's loop
+            struct Taken {
+                bool has;
+                int j;
+                float4 pj;
+                Nb nb;
+            };
+            // Moves the lane on to its next bits when those at hand are used up.
+            auto refill = [&]() {
+                if (wave_any(cur == 0)) {
+                    if (cur == 0) {
+                        if (pend != 0) {
+                            cur = pend;
+                            pend = 0;
+                            cbase += 32;
+                        } else if ((xw.y >> kHitSegShift) == (unsigned)cseg) {  // an extra word of this segment
+                            cur = xw.x;
+                            cbase = (cseg & 1) * ROWCAP + (int)(xw.y & ((1u << kHitSegShift) - 1u));
+                            xw = extra_at(++xk);
+                        } else if (cseg < r) {  // on to segment r, whose main word is `fw`
+                            cseg = r;
+                            cur = fw.x;
+                            pend = fw.y & ~kHitMainMask;
+                            cbase = (r & 1) * ROWCAP + 4 * (int)(fw.y & kHitMainMask);
+                        }
+                    }
+                }
+            };
+            // Takes the lane's next neighbour and starts the tile reads.  `part` 0: until every lane has reached
+            // segment r; 1: until fewer than kQuorum lanes have bits left (all of them in the last segment).
+            auto next = [&](Taken &T, int part) -> bool {
+                refill();
+                const bool has = cur != 0;
+                if (part == 0) {
+                    if (!wave_any(cseg < r)) return false;  // a lane moves on to r when it is through with r - 1
+                } else {
+                    const unsigned long long busy = __ballot(has);
+                    if (busy == 0ull || (r + 1 < nseg && __popcll(busy) < kQuorum)) return false;
+                }
+                const int k = __builtin_clz(cur | 1u);  // cur == 0: nothing to clear
+                cur &= ~(0x80000000u >> k);
+                const int t = has ? cbase + k : 0;
+                T.has = has;
+                T.j = has ? sg.start[cseg] + t - (cseg & 1) * ROWCAP : 0;  // (dropped for policies that ignore it)
+                T.nb = lds.nb[t];
+                if constexpr (kPos) T.pj = lds.pos[t];
+                return true;
+            };
+            auto eval = [&](const Taken &T) {
+                if (!T.has) return;
+                float4 pj;
+                if constexpr (kPos) pj = T.pj; else pj = T.nb.pos();
+                const float xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                const float d2 = xx * xx + xy * xy + xz * xz;
+                Policy::pair(A, P, S, false, FSA_TYPE_FLUID, T.j, xx, xy, xz, d2, pj, T.nb);
+            };
+            // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated
+            auto run = [&](int part) {
+                Taken T0, T1;
+                bool go = next(T0, part);
+                while (go) {
+                    const bool go1 = next(T1, part);
+                    eval(T0);
+                    if (!go1) break;
+                    go = next(T0, part);
+                    eval(T1);
+                }
+            };
+            run(0);
+            if (r + 1 < nseg) {
+                __syncthreads();  // everyone is done with the tile of segment r - 1
+                store((r + 1) & 1, sg.len[r + 1]);
+                if (r + 2 < nseg) fetch(sg.start[r + 2], sg.len[r + 2]);
+            }
+            run(1);
+            if (r + 1 < nseg) {
+                fw = fwn;
+                __syncthreads();  // the tile of segment r + 1 is visible
+            }
+        }
+    }
+    if constexpr (wall_words<Policy>::value) {
+        // the wall neighbours, in neighbour order (no barrier follows: a wavefront with particles at a wall ends later)
+        if (rec) {
+            const int ww = wallCount[index];
+            const uint2 *const wwp = hitWords + (size_t)blk * kHitSlots * BS + (size_t)(kMaxSegs + kHitExtra) * BS + tid;
+            for (int k = 0; k < ww; k++) {
+                const uint2 w = wwp[(size_t)k * BS];
+                unsigned m = w.x;
+                while (m) {  // four neighbours' loads in flight at a time
+                    constexpr int kAhead = 4;
+                    int js[kAhead];
+                    bool has[kAhead];
+#pragma unroll
+                    for (int u = 0; u < kAhead; u++) {
+                        has[u] = m != 0;
+                        const int b = __builtin_clz(m | 1u);
+                        if (has[u]) m &= ~(0x80000000u >> b);
+                        js[u] = has[u] ? (int)w.y + b : index;
+                    }
+                    float4 pj[kAhead];
+                    Nb nbr[kAhead];
+#pragma unroll
+                    for (int u = 0; u < kAhead; u++) {
+                        nbr[u] = Policy::load(A, js[u]);
+                        if constexpr (kPos) pj[u] = A.posType[js[u]]; else pj[u] = nbr[u].pos();
+                    }
+#pragma unroll
+                    for (int u = 0; u < kAhead; u++) {
+                        if (!has[u]) continue;
+                        const float xx = pi.x - pj[u].x, xy = pi.y - pj[u].y, xz = pi.z - pj[u].z;
+                        const float d2 = xx * xx + xy * xy + xz * xz;
+                        Policy::pair(A, P, S, false, FSA_TYPE_BOUNDARY, js[u], xx, xy, xz, d2, pj[u], nbr[u]);
+                    }
+                }
+            }
+        }
+    }
+    if (active) Policy::finish(A, P, index, S);
+}
+
 // The elements i, i + stride, i + 2 stride, ... below n, folded into `acc` in that order -- eight loads in flight at a
 // time (one dependent load per trip reads at a quarter of the memory rate); the order, and so every bit of a
 // floating-point sum, is that of the plain loop.
@@ -681,12 +921,29 @@ constexpr int kQueueDf = 48;  // 16-bit slots, as in the WCSPH force pass
 
 static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F32 && s->variant >= 1; }
 
-// Policy<float> over arrays A through the tiled kernel, or, with `lists`, through the recorded neighbour lists
-// (worth it for passes that run many times per sort; the policy must not reach any type beyond the support).
+// Does Policy replay the hit record in this solver?  (fsa_set_neighbour_lists(s, 0) makes every pass search.)
+template <typename Policy> static bool replays_hits(const Solver *s) {
+    return hit_replay<Policy>::value && s->use_lists && s->use_replay && s->precision == FSA_PRECISION_F32 &&
+           s->variant == 3 && !s->slab && s->sorted_valid && s->pf.rows && s->b.hitWords;
+}
+// What a pass that repeats between two sorts replays: the hit record or the neighbour lists, made here if stale.
+template <typename Policy> static int ensure_neighbours(Solver *s, bool lists = true) {
+    if (replays_hits<Policy>(s)) return ensure_hit_record(s);
+    return lists ? ensure_lists(s) : FSA_OK;
+}
+
+// Policy<float> over arrays A through the tiled kernel, or, with `lists`, through the hit record or the recorded
+// neighbour lists (worth it for passes that run many times per sort; the policy must not reach any type beyond the
+// support).
 template <typename Policy> static int run_tiled(Solver *s, const PassArrays<float> &A, bool lists) {
     const int unit = kXcds << s->xcd_run_log;
     const int nb = ((s->n + kTunedBS - 1) / kTunedBS + unit - 1) / unit * unit;
-    if (lists && s->use_lists && s->lists_valid) {
+    if (replays_hits<Policy>(s) && s->hits_valid) {
+        if constexpr (hit_replay<Policy>::value)
+            hipLaunchKernelGGL((hit_replay_kernel<Policy, kTunedBS, kRowCap>), dim3(nb), dim3(kTunedBS), 0, s->stream,
+                               s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, (const uint2 *)s->b.hitWords,
+                               s->b.hitCount, s->b.wallCount, s->xcd_run_log);
+    } else if (lists && s->use_lists && s->lists_valid) {
         if constexpr (row_replay<Policy>::value)
             hipLaunchKernelGGL((list_rows_kernel<Policy, kTunedBS, kRowCap, kListSlots>), dim3(nb), dim3(kTunedBS), 0,
                                s->stream, s->pf, s->n, A, s->b.cellStart, s->b.sortedHash, s->b.nbList, s->b.nbCount,
@@ -708,10 +965,8 @@ template <typename Policy> static int run_tiled(Solver *s, const PassArrays<floa
 }
 
 template <typename Policy> static int launch_tuned(Solver *s, const char *tag, bool lists = false) {
-    if (lists) {
-        const int rc = ensure_lists(s);
-        if (rc) return rc;
-    }
+    const int rc = ensure_neighbours<Policy>(s, lists);
+    if (rc) return rc;
     ScopedTimer t(s, tag);
     return run_tiled<Policy>(s, arrays_of<float>(s), lists);
 }

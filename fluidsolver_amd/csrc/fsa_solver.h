@@ -67,6 +67,7 @@ struct Buffers {
     unsigned char *wallCount = nullptr; // wall words per particle
     int *wallList = nullptr;            // [0] = count, then the particles that have wall words
     void *wallForce = nullptr;          // float4 per particle: the wall pass's sum (read where wallCount > 0)
+    void *applyRec = nullptr;           // float4 per particle: what applyPStiff reads of a neighbour while the hit record is in use
     int *scanTmp = nullptr;
     int *undefBlockCount = nullptr;
     int *undefBlockStart = nullptr;
@@ -113,6 +114,8 @@ struct Solver {
     bool pd_valid = false;  // pd[] matches density / pressure / mass of the current arrays ...
     bool pd_fast = false;   // ... in the fast flavour's layout
     bool use_lists = true;      // passes that repeat between two sorts replay recorded neighbour lists
+    bool use_replay = true;     // ... or, where the pass allows it, the hit record of the variant-3 density pass
+                                // (hit_replay_kernel in fsa_pass.h); FSA_HIT_REPLAY=0, read once by fsa_create, turns it off
     bool lists_valid = false;   // nbList / nbCount describe the current arrays and positions
     bool hits_valid = false;    // hitWords / hitCount describe the current arrays and positions
     int wall_mode = 0;             // where the variant-3 passes sum the wall neighbours: 0 by size (fsa_sph_fast.hip), 1 in
@@ -227,6 +230,7 @@ int ensure_lists(Solver *s);  // builds the neighbour lists if they are enabled 
 int launch_density_tuned(Solver *s);
 int launch_density_fast(Solver *s);
 int launch_force_fast(Solver *s);
+int ensure_hit_record(Solver *s);  // records the hits of the sorted state if the record is stale (no density written)
 int launch_fused_probe(Solver *s, int mode);  // measurement only (fsa_sph_fast.hip)
 int launch_density_rigid_tuned(Solver *s);
 int launch_force_tuned(Solver *s);

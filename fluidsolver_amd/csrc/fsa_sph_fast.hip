@@ -852,6 +852,12 @@ int launch_density_fast(Solver *s) {
     return FSA_OK;
 }
 
+int ensure_hit_record(Solver *s) {
+    if (s->hits_valid || s->grid_n() == 0) return FSA_OK;
+    ScopedTimer t(s, "record_hits");
+    return launch_density_record<false>(s);
+}
+
 // needs pd[] in the fast layout (the caller sees to that)
 int launch_force_fast(Solver *s) {
     if (s->grid_n() == 0) return FSA_OK;

@@ -335,7 +335,16 @@ int fsa_set_variant(fsa_solver *s, int variant);
  * and in the reference's neighbour order, every particle within the support radius, and the passes replay
  * that list instead of searching again.  Same pair arithmetic in the same order: results are bit for bit
  * those of the searching kernels.  Costs 128 bytes of device memory per particle of the solver's capacity,
- * allocated when first used.  The WCSPH step (two passes per sort) does not use them. */
+ * allocated when first used.  The WCSPH step (two passes per sort) does not use them.
+ *
+ * On kernel variant 3 (solvers that are not slab solvers) the passes of the DFSPH step replay the hit record
+ * of the variant-3 density pass instead (one bit per candidate of each neighbour row, made once per sort
+ * without computing a density; the neighbours come from row tiles in LDS as in the WCSPH force pass) and no
+ * list is built: same pair arithmetic in the same order.  The record marks a neighbour on the fused squared
+ * distance and the list on the same with a slack of 2e-6, so a pair whose two roundings of the distance
+ * straddle the support radius (its term is about 1e-14 of the others) is the only thing the two can differ in.
+ *
+ * enabled: 0 = every pass searches, 1 = lists, and the hit record where it applies (default), 2 = lists only. */
 int fsa_set_neighbour_lists(fsa_solver *s, int enabled);
 
 /* ---- z-slab decomposition: one solver per GPU ---------------------------

@@ -201,3 +201,104 @@ def test_blocks_with_segments_of_their_own_replay_the_same_bits(step, variant):
         s.close()
     for k in names:
         assert got[0][k].tobytes() == got[1][k].tobytes(), k
+
+
+# ---- the hit record of the variant-3 density pass, replayed by the DFSPH passes ---------------------------------
+
+def run_dfsph(sc, mode, steps, variant=3):
+    """mode: "replay" (the default of variant 3), "lists" (lists only) or "search"; returns the results and the
+    names of the kernels that ran"""
+    p, s = gpu_solver(sc)
+    s.set_variant(variant)
+    s.set_neighbour_lists(mode != "search", replay=mode == "replay")
+    s.timing_enable(True)
+    s.setup_dfsph()
+    s.step_dfsph(steps)
+    out = {k: s.get(k) for k in DFSPH_OUT}
+    ran = set(s.timing_read())
+    s.close()
+    return out, ran
+
+
+def crowded_dam():
+    sc = scenes.jittered(scenes.dam_break(16, 12, 10), seed=43, pos_jitter=0.15, vel_scale=0.3, fluid_only=True)
+    pos = np.array(sc["pos"])
+    fl = np.where(np.asarray(sc["type"]) == 0)[0][:500]
+    c = pos[fl].mean(0)
+    pos[fl] = (c + (pos[fl] - c) * np.float32(0.4)).astype(np.float32)  # ranges of far more than 57 candidates
+    return dict(sc, pos=pos)
+
+
+REPLAY_SCENES = {
+    "jittered": lambda: scenes.jittered(scenes.dam_break(16, 12, 10), seed=43, pos_jitter=0.15, vel_scale=0.3,
+                                        fluid_only=True),
+    "at_walls": lambda: scenes.jittered(scenes.dam_break(14, 12, 10, tank_x_factor=2.0), seed=21, pos_jitter=0.2,
+                                        vel_scale=1.0),
+    "crowded": crowded_dam,
+    "large_tiles": lambda: scenes.dam_break(32, 24, 32),    # rows beyond a tile: two tiles per row
+    "own_segments": lambda: scenes.dam_break(48, 24, 32),   # blocks with segments of their own
+}
+
+
+@pytest.mark.parametrize("name", list(REPLAY_SCENES))
+def test_dfsph_replaying_the_hit_record_equals_dfsph_with_lists_and_with_search(name):
+    """on variant 3 the passes of the DFSPH step (density and factor, non-pressure force with its wall neighbours, the
+    density-change passes, applyPStiff) take their neighbours from the hit record of the WCSPH density pass, made once
+    per sort: the bits of the list replay and of the searching kernels, particles without a record (crowded
+    neighbourhoods, blocks that cannot be tiled) included"""
+    sc = REPLAY_SCENES[name]()
+    steps = 3 if len(sc["pos"]) < 20000 else 2
+    a, ran_a = run_dfsph(sc, "replay", steps)
+    b, ran_b = run_dfsph(sc, "lists", steps)
+    c, ran_c = run_dfsph(sc, "search", steps)
+    assert "record_hits" in ran_a and "list_build" not in ran_a
+    assert "list_build" in ran_b and "record_hits" not in ran_b
+    assert "list_build" not in ran_c and "record_hits" not in ran_c
+    for k in DFSPH_OUT:
+        assert a[k].tobytes() == b[k].tobytes(), k
+        assert a[k].tobytes() == c[k].tobytes(), k
+    if name == "crowded":  # some particles have no record and walk the cells inside the replay kernels
+        p, s = gpu_solver(sc)
+        s.sort_particles()
+        s.compute_pressure()
+        assert (s.get("hitCount") < 0).sum() > 0
+        s.close()
+
+
+def test_hit_record_is_made_again_after_positions_change_without_a_sort():
+    sc = REPLAY_SCENES["jittered"]()
+    outs = []
+    for mode in ("replay", "search"):
+        p, s = gpu_solver(sc)
+        s.set_neighbour_lists(mode != "search")
+        s.setup_dfsph()
+        s.compute_non_pressure_force()  # records (when enabled)
+        pos = s.get("pos")
+        rng = np.random.default_rng(3)
+        s.set("pos", (pos + rng.normal(0, 0.0005, pos.shape)).astype(np.float32))
+        s.sort_particles()
+        s.compute_density_alpha()
+        outs.append({k: s.get(k) for k in ("density", "DF_factor", "uniqueId")})
+        s.close()
+    for k in outs[0]:
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+def test_wcsph_force_after_dfsph_passes_still_finds_its_record():
+    """the DFSPH passes keep their packed records out of the buffers of the WCSPH record while they replay it: a WCSPH
+    force pass on the same sorted state gives what it gives without them"""
+    sc = REPLAY_SCENES["at_walls"]()
+    p, a = gpu_solver(sc)
+    p, b = gpu_solver(sc)
+    for s in (a, b):
+        s.sort_particles()
+        s.compute_pressure()
+    a.compute_density_alpha()
+    a.compute_non_pressure_force()
+    a.solve_density_stiff()
+    a.apply_pstiff()
+    for s in (a, b):
+        s.compute_force()
+    assert a.get("force").tobytes() == b.get("force").tobytes()
+    a.close()
+    b.close()
