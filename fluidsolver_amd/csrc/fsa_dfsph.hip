@@ -336,6 +336,10 @@ struct ApplyUniformPolicy {
     static constexpr bool kPosInNb = true;
     static constexpr bool kDeepReplay = true;
     static constexpr bool kHitReplay = true;
+#ifndef FSA_APPLY_PER
+#define FSA_APPLY_PER 2
+#endif
+    static constexpr int kReplayPer = FSA_APPLY_PER;
     static __device__ __forceinline__ int reach(int tj) { return tj == FSA_TYPE_FLUID ? 1 : 0; }
     struct Self { T wi, fx, fy, fz, mass; };
     struct Nb {

@@ -639,6 +639,11 @@ __global__ __launch_bounds__(BS, FSA_ROWS_BLOCKS) void list_rows_kernel(DevParam
 #ifndef FSA_REPLAY_BLOCKS
 #define FSA_REPLAY_BLOCKS 6
 #endif
+// `static constexpr int kReplayPer = 2`: a lane takes two neighbours per trip of the loop (the trip's tests and
+// ballots are shared; pays for a light `pair` with few registers).
+template <typename Policy, typename = void> struct replay_per : std::integral_constant<int, 1> {};
+template <typename Policy> struct replay_per<Policy, std::void_t<decltype(Policy::kReplayPer)>>
+    : std::integral_constant<int, Policy::kReplayPer> {};
 template <typename Nb, int ROWCAP, bool POS> struct ReplayLds {
     RowShared<1, 4, false> sh;  // only its row table is used here
     Segments sg;
@@ -656,6 +661,7 @@ __global__ __launch_bounds__(BS, FSA_REPLAY_BLOCKS) void hit_replay_kernel(DevPa
     constexpr bool kPos = !pos_in_nb<Policy>::value;  // positions in a tile of their own
     constexpr int kRegs = row_regs<BS, ROWCAP - kChunk>();
     constexpr int kQuorum = 40;
+    constexpr int kPer = replay_per<Policy>::value;  // neighbours a lane takes per trip
     __shared__ ReplayLds<Nb, ROWCAP, kPos> lds;
     static_assert((kPos ? sizeof(float4) : sizeof(Nb)) * 2 * ROWCAP >= sizeof(int) * (20 * kSparseRuns + 16),
                   "a tile is the scratch space of sparse_segments");
@@ -736,10 +742,10 @@ __global__ __launch_bounds__(BS, FSA_REPLAY_BLOCKS) void hit_replay_kernel(DevPa
             uint2 fwn = make_uint2(0u, 0u);
             if (r + 1 < nseg && rec) fwn = wp[(size_t)(r + 1) * BS];  // in flight during this segment's loop
             struct Taken {
-                bool has;
-                int j;
-                float4 pj;
-                Nb nb;
+                bool has[kPer];
+                int j[kPer];
+                float4 pj[kPer];
+                Nb nb[kPer];
             };
             // Moves the lane on to its next bits when those at hand are used up.
             auto refill = [&]() {
@@ -773,22 +779,35 @@ __global__ __launch_bounds__(BS, FSA_REPLAY_BLOCKS) void hit_replay_kernel(DevPa
                     const unsigned long long busy = __ballot(has);
                     if (busy == 0ull || (r + 1 < nseg && __popcll(busy) < kQuorum)) return false;
                 }
-                const int k = __builtin_clz(cur | 1u);  // cur == 0: nothing to clear
-                cur &= ~(0x80000000u >> k);
-                const int t = has ? cbase + k : 0;
-                T.has = has;
-                T.j = has ? sg.start[cseg] + t - (cseg & 1) * ROWCAP : 0;  // (dropped for policies that ignore it)
-                T.nb = lds.nb[t];
-                if constexpr (kPos) T.pj = lds.pos[t];
+#pragma unroll
+                for (int u = 0; u < kPer; u++) {
+                    if (u > 0) {  // the bits beyond the first 32 of the main word follow without a trip of their own
+                        const bool on = cur == 0 && pend != 0;
+                        cur = on ? pend : cur;
+                        cbase += on ? 32 : 0;
+                        pend = on ? 0u : pend;
+                    }
+                    const bool hu = cur != 0;
+                    const int k = __builtin_clz(cur | 1u);  // cur == 0: nothing to clear
+                    cur &= ~(0x80000000u >> k);
+                    const int t = hu ? cbase + k : 0;
+                    T.has[u] = hu;
+                    T.j[u] = hu ? sg.start[cseg] + t - (cseg & 1) * ROWCAP : 0;  // (dropped for policies that ignore it)
+                    T.nb[u] = lds.nb[t];
+                    if constexpr (kPos) T.pj[u] = lds.pos[t];
+                }
                 return true;
             };
             auto eval = [&](const Taken &T) {
-                if (!T.has) return;
-                float4 pj;
-                if constexpr (kPos) pj = T.pj; else pj = T.nb.pos();
-                const float xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
-                const float d2 = xx * xx + xy * xy + xz * xz;
-                Policy::pair(A, P, S, false, FSA_TYPE_FLUID, T.j, xx, xy, xz, d2, pj, T.nb);
+#pragma unroll
+                for (int u = 0; u < kPer; u++) {
+                    if (!T.has[u]) continue;
+                    float4 pj;
+                    if constexpr (kPos) pj = T.pj[u]; else pj = T.nb[u].pos();
+                    const float xx = pi.x - pj.x, xy = pi.y - pj.y, xz = pi.z - pj.z;
+                    const float d2 = xx * xx + xy * xy + xz * xz;
+                    Policy::pair(A, P, S, false, FSA_TYPE_FLUID, T.j[u], xx, xy, xz, d2, pj, T.nb[u]);
+                }
             };
             // two stages, roles rotating: the next neighbour's tile reads are in flight while one is evaluated
             auto run = [&](int part) {
