@@ -673,6 +673,12 @@ __global__ __launch_bounds__(BS, FSA_REPLAY_BLOCKS) void hit_replay_kernel(DevPa
     if (b0 >= n) return;  // padding blocks of the rounded-up grid
     const int nb = min(BS, n - b0);
     const int index = b0 + tid;
+    if (P.nz != P.gres[2]) {
+        // a slab solver: the record leaves out the blocks that lie entirely in the outer halo layers, whose results
+        // nobody reads (the halo layers get every pass's results from the slabs that own them)
+        const unsigned hlo = (unsigned)sortedHash[b0], hhi = (unsigned)sortedHash[b0 + nb - 1];
+        if (hhi != (unsigned)FSA_GRID_UNDEF && run_unneeded(P, hlo, hhi, 1)) return;
+    }
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     bool active = false;
     if (index < n) {
@@ -943,7 +949,7 @@ static bool use_tiles(const Solver *s) { return s->precision == FSA_PRECISION_F3
 // Does Policy replay the hit record in this solver?  (fsa_set_neighbour_lists(s, 0) makes every pass search.)
 template <typename Policy> static bool replays_hits(const Solver *s) {
     return hit_replay<Policy>::value && s->use_lists && s->use_replay && s->precision == FSA_PRECISION_F32 &&
-           s->variant == 3 && !s->slab && s->sorted_valid && s->pf.rows && s->b.hitWords;
+           s->variant == 3 && s->sorted_valid && s->pf.rows && s->b.hitWords;
 }
 // What a pass that repeats between two sorts replays: the hit record or the neighbour lists, made here if stale.
 template <typename Policy> static int ensure_neighbours(Solver *s, bool lists = true) {

@@ -337,7 +337,7 @@ int fsa_set_variant(fsa_solver *s, int variant);
  * those of the searching kernels.  Costs 128 bytes of device memory per particle of the solver's capacity,
  * allocated when first used.  The WCSPH step (two passes per sort) does not use them.
  *
- * On kernel variant 3 (solvers that are not slab solvers) the passes of the DFSPH step replay the hit record
+ * On kernel variant 3 the passes of the DFSPH step replay the hit record
  * of the variant-3 density pass instead (one bit per candidate of each neighbour row, made once per sort
  * without computing a density; the neighbours come from row tiles in LDS as in the WCSPH force pass) and no
  * list is built: same pair arithmetic in the same order.  The record marks a neighbour on the fused squared

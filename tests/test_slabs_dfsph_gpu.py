@@ -49,11 +49,16 @@ def test_dfsph_on_local_slabs_equals_plain_solver(world, scene, variant):
     ranks = [slabs.SlabSolver(sc, r, world, None, lambda P, held, cap: slabs.HipSlabBackend(P, held, cap, 0, variant),
                               exchange_buffers=False) for r in range(world)]
     team = slabs.DfsphSlabs(ranks, slabs.LocalComm())
+    for ss in ranks:
+        ss.backend.solver.timing_enable(True)
     team.setup()
     team.step(STEPS)
     assert sum(ss.lost for ss in ranks) == 0
     if world > 1:
         assert sum(ss.sent_records for ss in ranks) > 0
+    # on variant 3 the slabs' passes replay the hit record (made for the layers a slab computes on), else the lists
+    ran = [set(ss.backend.solver.timing_read()) for ss in ranks]
+    assert all(("record_hits" in r) == (variant == 3) and ("list_build" in r) == (variant != 3) for r in ran)
     assert team.density_rounds == dens and team.divergence_rounds == div
     assert max(dens) + max(div) > 0  # (the loops really ran)
     assert_same_dfsph_bits([owned_dfsph(ss) for ss in ranks], ref)
