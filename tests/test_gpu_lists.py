@@ -302,3 +302,22 @@ def test_wcsph_force_after_dfsph_passes_still_finds_its_record():
     assert a.get("force").tobytes() == b.get("force").tobytes()
     a.close()
     b.close()
+
+
+def test_neighbour_mode_values_and_a_solver_whose_size_is_no_multiple_of_a_block():
+    """fsa_set_neighbour_lists takes 0, 1 or 2 and nothing else; a solver of 1000 particles (three full blocks and a
+    part) and one of 7 (less than a wavefront) replay the record like any other"""
+    sc = scenes.jittered(scenes.dam_break(10, 10, 10, walls=False), seed=5, pos_jitter=0.1, vel_scale=0.2)
+    p, s = gpu_solver(sc)
+    for bad in (-1, 3):
+        with pytest.raises(capi.FsaError):
+            capi.check(s.lib.fsa_set_neighbour_lists(s._h, bad))
+    s.close()
+    for n in (1000, 7):
+        sub = {k: (np.asarray(v)[:n] if k != "params" and hasattr(v, "__len__") and len(v) == len(sc["pos"]) else v)
+               for k, v in sc.items()}
+        a, ran = run_dfsph(sub, "replay", 3)
+        b, _ = run_dfsph(sub, "search", 3)
+        assert "record_hits" in ran
+        for k in DFSPH_OUT:
+            assert a[k].tobytes() == b[k].tobytes(), (n, k)
